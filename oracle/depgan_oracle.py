@@ -1,0 +1,474 @@
+"""CPU restatement of the DEP-GAN two-critic WGAN-GP training step (autograd form).
+
+TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.  PARITY UNPINNED (no
+reference golden vectors exist; Keras/TF cannot run here).
+
+Follows /root/reference/DEP-GAN_PROB_IM_twoCritics_training_4fold.py ("GT"):
+  * layer helpers            GT:254-312
+  * critic  Dis_C2D_FCN1     GT:316-345
+  * generator Gen_UNet2D     GT:349-498
+  * losses / updates / the four K.function closures   GT:523-598
+and the Keras-2.x/TF-1.x default semantics listed in SURVEY.md Appendix B
+(channels_last, HWIO kernels, Conv2DTranspose kernel (kh,kw,Cout,Cin), BN
+eps=1e-3 in inference mode because no closure feeds K.learning_phase(),
+Dropout identity in phase 0, Keras Adam with epsilon 1e-7).
+
+All tensors at this module's boundary are NumPy, NHWC, Keras layouts.  torch
+(CPU, fp32 by default) is used as the array/autograd engine only.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3          # keras BatchNormalization default epsilon (App. B.3)
+ADAM_EPS = 1e-7        # K.epsilon() (App. B.6)
+NOISE_SIZE = 32        # GT:41
+
+# ----------------------------------------------------------------------------
+# Layer tables (GT:316-345, GT:349-498)
+# ----------------------------------------------------------------------------
+# film key -> suffix used in the noise-head layer names (GT:363-395)
+NOISE_HEADS = [  # creation order, (suffix, width multiplier)
+    ("add_m3", 3), ("mul_m3", 3), ("add_m2", 2), ("mul_m2", 2),
+    ("add_m1", 1), ("mul_m1", 1), ("add", 4), ("mul", 4),
+    ("add_p3", 3), ("mul_p3", 3), ("add_p2", 2), ("mul_p2", 2),
+    ("add_p1", 1), ("mul_p1", 1),
+]
+
+# Generator trunk, in forward order.  kind: conv (conv+bn+relu), film
+# (conv+bn, FiLM, relu, + residual), pool, deconv (2x2 s2 + bn + relu, then
+# concat with the named skip), head (1x1 conv + tanh/softmax).
+def gen_trunk(nicg=1, fm=32, nc_out=1):
+    f1, f2, f3, f4 = fm, 2 * fm, 3 * fm, 4 * fm
+    return [
+        ("conv", "gen_0", nicg, f1), ("film", "gen_noise_m1", f1, f1, "m1"),
+        ("conv", "gen_1", f1, f1), ("pool", "skip1"),
+        ("conv", "gen_2", f1, f2), ("film", "gen_noise_m2", f2, f2, "m2"),
+        ("conv", "gen_3", f2, f2), ("pool", "skip2"),
+        ("conv", "gen_4", f2, f3), ("film", "gen_noise_m3", f3, f3, "m3"),
+        ("conv", "gen_5", f3, f3), ("pool", "skip3"),
+        ("conv", "gen_8", f3, f4), ("film", "gen_noise_p4", f4, f4, ""),
+        ("conv", "gen_9", f4, f4),
+        ("deconv", "de_gen_9", f4, f4, "skip3"),
+        ("conv", "gen_10", f4 + f3, f3), ("film", "gen_noise_p3", f3, f3, "p3"),
+        ("conv", "gen_11", f3, f3),
+        ("deconv", "de_gen_11", f3, f3, "skip2"),
+        ("conv", "gen_14", f3 + f2, f2), ("film", "gen_noise_p2", f2, f2, "p2"),
+        ("conv", "gen_15", f2, f2),
+        ("deconv", "de_gen_15", f2, f2, "skip1"),
+        ("conv", "gen_16", f2 + f1, f1), ("film", "gen_noise_p1", f1, f1, "p1"),
+        ("conv", "gen_17", f1, f1),
+        ("head", "gen_segmentation", f1, nc_out),
+    ]
+
+# Critic trunk (GT:319-339): (name, k, cin, cout, pool_after)
+DIS_TRUNK = [
+    ("dis_0a", 5, 1, 16, False), ("dis_0b", 5, 16, 16, True),
+    ("dis_1a", 5, 16, 32, False), ("dis_1b", 5, 32, 32, True),
+    ("dis_2", 3, 32, 64, False), ("dis_3", 3, 64, 64, True),
+    ("dis_4", 3, 64, 128, False), ("dis_5", 3, 128, 128, True),
+    ("dis_6", 3, 128, 256, False), ("dis_7", 3, 256, 256, False),
+    ("dis_8", 3, 256, 256, False),
+]
+
+
+def film_names(key):
+    sfx = ("_" + key) if key else ""
+    return "noise_2_mul" + sfx, "noise_2_add" + sfx
+
+
+# ----------------------------------------------------------------------------
+# Parameter construction (Keras layouts; App. B.1, B.7)
+# ----------------------------------------------------------------------------
+def _glorot_uniform(rng, shape, fan_in, fan_out):
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def _he_normal(rng, shape, fan_in):
+    # keras he_normal = truncated normal(+-2 sigma), stddev sqrt(2/fan_in)/.8796
+    std = math.sqrt(2.0 / fan_in) / 0.87962566103423978
+    v = rng.standard_normal(size=shape)
+    bad = np.abs(v) > 2
+    while bad.any():
+        v[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(v) > 2
+    return (v * std).astype(np.float32)
+
+
+def _bn(P, name, c, rng, randomize):
+    if randomize:  # make phase-0 BN a non-trivial affine
+        P[name + "/gamma"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        P[name + "/beta"] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        P[name + "/moving_mean"] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        P[name + "/moving_variance"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    else:
+        P[name + "/gamma"] = np.ones(c, np.float32)
+        P[name + "/beta"] = np.zeros(c, np.float32)
+        P[name + "/moving_mean"] = np.zeros(c, np.float32)
+        P[name + "/moving_variance"] = np.ones(c, np.float32)
+
+
+def init_generator(seed, nicg=1, fm=32, nc_out=1, randomize_bn=True, bias_std=0.0):
+    """Parameters of Gen_UNet2D((256,256,nicg),(32,1),fm,nc_out), GT:349-498.
+    Canonical order: noise MLP (f0, f1, 14 heads in creation order) then the
+    trunk in forward order.  Keys are '<keras layer name>/<weight name>'."""
+    rng = np.random.default_rng(seed)
+    P = OrderedDict()
+
+    def dense(name, fin, fout):
+        P["dense_" + name + "/kernel"] = _he_normal(rng, (fin, fout), fin)
+        P["dense_" + name + "/bias"] = (bias_std * rng.standard_normal(fout)).astype(np.float32)
+        _bn(P, "dense_bn_" + name, fout, rng, randomize_bn)
+
+    dense("noise_1_add_f0", 1, fm)           # GT:358
+    dense("noise_1_add_f1", fm, fm)          # GT:359
+    for sfx, mult in NOISE_HEADS:            # GT:363-395
+        dense("noise_2_" + sfx, NOISE_SIZE * fm, fm * mult)
+    for ent in gen_trunk(nicg, fm, nc_out):
+        kind, name = ent[0], ent[1]
+        if kind in ("conv", "film"):
+            ci, co = ent[2], ent[3]
+            P["conv2d_" + name + "/kernel"] = _glorot_uniform(rng, (3, 3, ci, co), 9 * ci, 9 * co)
+            P["conv2d_" + name + "/bias"] = (bias_std * rng.standard_normal(co)).astype(np.float32)
+            _bn(P, "bn_" + name, co, rng, randomize_bn)
+        elif kind == "deconv":
+            ci, co = ent[2], ent[3]
+            # Conv2DTranspose kernel layout (kh, kw, Cout, Cin)  (App. B.1)
+            P["deconv2d_" + name + "/kernel"] = _glorot_uniform(rng, (2, 2, co, ci), 4 * co, 4 * ci)
+            P["deconv2d_" + name + "/bias"] = (bias_std * rng.standard_normal(co)).astype(np.float32)
+            _bn(P, "bn_" + name, co, rng, randomize_bn)
+        elif kind == "head":
+            ci, co = ent[2], ent[3]
+            P[name + "/kernel"] = _glorot_uniform(rng, (1, 1, ci, co), ci, co)
+            P[name + "/bias"] = (bias_std * rng.standard_normal(co)).astype(np.float32)
+    return P
+
+
+def init_critic(seed, bias_std=0.0, img=256):
+    """Parameters of Dis_C2D_FCN1((img,img,1)), GT:316-345 (img=256 in the
+    reference; smaller img only for fast tests: Flatten is (img/16)^2 long)."""
+    rng = np.random.default_rng(seed)
+    P = OrderedDict()
+    for name, k, ci, co, _ in DIS_TRUNK:
+        P["conv2d_" + name + "/kernel"] = _glorot_uniform(rng, (k, k, ci, co), k * k * ci, k * k * co)
+        P["conv2d_" + name + "/bias"] = (bias_std * rng.standard_normal(co)).astype(np.float32)
+    P["dis_9/kernel"] = _he_normal(rng, (1, 1, 256, 1), 256)          # GT:339
+    P["dis_9/bias"] = (bias_std * rng.standard_normal(1)).astype(np.float32)
+    nflat = (img // 16) ** 2
+    P["dense_1/kernel"] = _he_normal(rng, (nflat, 1), nflat)          # GT:342
+    P["dense_1/bias"] = (bias_std * rng.standard_normal(1)).astype(np.float32)
+    return P
+
+
+def trainable_names(P):
+    return [k for k in P if not (k.endswith("/moving_mean") or k.endswith("/moving_variance"))]
+
+
+# ----------------------------------------------------------------------------
+# torch helpers
+# ----------------------------------------------------------------------------
+def to_torch(P, dtype=torch.float32, requires_grad=False):
+    T = OrderedDict()
+    for k, v in P.items():
+        t = torch.tensor(np.asarray(v), dtype=dtype)
+        if requires_grad and not (k.endswith("/moving_mean") or k.endswith("/moving_variance")):
+            t.requires_grad_(True)
+        T[k] = t
+    return T
+
+
+def _t(a, dtype):
+    return a if isinstance(a, torch.Tensor) else torch.tensor(np.asarray(a), dtype=dtype)
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1)
+
+
+def _conv_same(x, w_hwio, b):
+    """keras Conv2D(padding='same', stride 1), NCHW in/out, HWIO kernel."""
+    k = w_hwio.shape[0]
+    return F.conv2d(x, w_hwio.permute(3, 2, 0, 1), b, padding=k // 2)
+
+
+def _bn_infer(x, T, name, ch_axis=1):
+    """phase-0 BN: tf.nn.batch_normalization form  x*inv + (beta - mean*inv)."""
+    inv = T[name + "/gamma"] * torch.rsqrt(T[name + "/moving_variance"] + BN_EPS)
+    sh = T[name + "/beta"] - T[name + "/moving_mean"] * inv
+    shape = [1] * x.dim()
+    shape[ch_axis] = -1
+    return x * inv.view(shape) + sh.view(shape)
+
+
+# ----------------------------------------------------------------------------
+# Generator forward (phase 0)  GT:349-498
+# ----------------------------------------------------------------------------
+def noise_mlp(T, z):
+    """z (B,32,1) -> dict head-name -> (B, C).  GT:358-395, App. B.5."""
+    h = z @ T["dense_noise_1_add_f0/kernel"] + T["dense_noise_1_add_f0/bias"]     # (B,32,fm)
+    h = torch.relu(_bn_infer(h, T, "dense_bn_noise_1_add_f0", ch_axis=2))
+    h = h @ T["dense_noise_1_add_f1/kernel"] + T["dense_noise_1_add_f1/bias"]
+    h = torch.relu(_bn_infer(h, T, "dense_bn_noise_1_add_f1", ch_axis=2))
+    flat = h.reshape(h.shape[0], -1)                                              # (B,1024) (pos,feat)
+    heads = {}
+    for sfx, _ in NOISE_HEADS:
+        n = "noise_2_" + sfx
+        v = flat @ T["dense_" + n + "/kernel"] + T["dense_" + n + "/bias"]
+        heads[n] = _bn_infer(v, T, "dense_bn_" + n, ch_axis=1)
+    return heads
+
+
+def g_forward_t(T, x, z, nicg=1, fm=32, nc_out=1, head="tanh", taps=None):
+    """x (B,H,W,nicg) NHWC torch, z (B,32,1) -> (B,H,W,nc_out) NHWC torch."""
+    heads = noise_mlp(T, z)
+    a = _nchw(x)
+    skips = {}
+    for ent in gen_trunk(nicg, fm, nc_out):
+        kind, name = ent[0], ent[1]
+        if kind == "conv":
+            a = _conv_same(a, T["conv2d_" + name + "/kernel"], T["conv2d_" + name + "/bias"])
+            a = torch.relu(_bn_infer(a, T, "bn_" + name))
+        elif kind == "film":
+            mul_n, add_n = film_names(ent[4])
+            u = _conv_same(a, T["conv2d_" + name + "/kernel"], T["conv2d_" + name + "/bias"])
+            u = _bn_infer(u, T, "bn_" + name)
+            v = u * heads[mul_n][:, :, None, None] + heads[add_n][:, :, None, None]
+            a = torch.relu(v) + a
+        elif kind == "pool":
+            skips[name] = a
+            a = F.max_pool2d(a, 2)
+        elif kind == "deconv":
+            w = T["deconv2d_" + name + "/kernel"]            # (kh,kw,Cout,Cin)
+            a = F.conv_transpose2d(a, w.permute(3, 2, 0, 1), T["deconv2d_" + name + "/bias"], stride=2)
+            a = torch.relu(_bn_infer(a, T, "bn_" + name))
+            a = torch.cat([a, skips[ent[4]]], dim=1)         # GT:450 order [deconv, skip]
+        elif kind == "head":
+            a = _conv_same(a, T[name + "/kernel"], T[name + "/bias"])
+            if head == "tanh":
+                a = torch.tanh(a)
+            elif head == "softmax":
+                a = torch.softmax(a, dim=1)
+        if taps is not None:
+            taps[name] = a
+    return _nhwc(a)
+
+
+def d_forward_t(T, img, taps=None):
+    """img (B,H,W,1) NHWC torch -> (B,1).  GT:316-345."""
+    a = _nchw(img)
+    for name, k, ci, co, pool in DIS_TRUNK:
+        a = torch.relu(_conv_same(a, T["conv2d_" + name + "/kernel"], T["conv2d_" + name + "/bias"]))
+        if taps is not None:
+            taps[name] = a
+        if pool:
+            a = F.max_pool2d(a, 2)
+    a = _conv_same(a, T["dis_9/kernel"], T["dis_9/bias"])       # (B,1,h,w)
+    flat = _nhwc(a).reshape(a.shape[0], -1)                     # Flatten of NHWC
+    return flat @ T["dense_1/kernel"] + T["dense_1/bias"]
+
+
+# numpy-facing wrappers -------------------------------------------------------
+def g_predict(P, x, z, nicg=1, fm=32, nc_out=1, head="tanh", dtype=torch.float32):
+    with torch.no_grad():
+        T = to_torch(P, dtype)
+        return g_forward_t(T, _t(x, dtype), _t(z, dtype), nicg, fm, nc_out, head).numpy()
+
+
+def d_predict(P, img, dtype=torch.float32):
+    with torch.no_grad():
+        T = to_torch(P, dtype)
+        return d_forward_t(T, _t(img, dtype)).numpy()
+
+
+# ----------------------------------------------------------------------------
+# Keras Adam (App. B.6)
+# ----------------------------------------------------------------------------
+class KerasAdam:
+    def __init__(self, names, lr, beta_1=0.0, beta_2=0.9, eps=ADAM_EPS):
+        self.lr, self.b1, self.b2, self.eps = lr, beta_1, beta_2, eps
+        self.iterations = 0
+        self.names = list(names)
+        self.m = {}
+        self.v = {}
+
+    def apply(self, P, grads):
+        """P: dict name->np array (updated in place); grads: dict name->np array."""
+        t = self.iterations + 1
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        for n in self.names:
+            g = np.asarray(grads[n], dtype=P[n].dtype)
+            m = self.m.get(n, np.zeros_like(P[n]))
+            v = self.v.get(n, np.zeros_like(P[n]))
+            m = self.b1 * m + (1.0 - self.b1) * g
+            v = self.b2 * v + (1.0 - self.b2) * g * g
+            P[n] = (P[n] - lr_t * m / (np.sqrt(v) + self.eps)).astype(P[n].dtype)
+            self.m[n], self.v[n] = m, v
+        self.iterations = t
+
+
+# ----------------------------------------------------------------------------
+# Loss graphs  GT:523-598
+# ----------------------------------------------------------------------------
+def _critic_loss_t(TD, real, fake, ep, delta):
+    """WGAN-GP critic loss on (real, fake) images.  GT:536-547 / GT:555-566.
+    Returns (loss, loss_real, loss_fake, grad_penalty, norm per sample)."""
+    mixed = ep * real + (1.0 - ep) * fake
+    mixed = mixed.detach().requires_grad_(True)
+    loss_real = d_forward_t(TD, real).mean()
+    loss_fake = d_forward_t(TD, fake).mean()
+    out_mixed = d_forward_t(TD, mixed)
+    (grad_mixed,) = torch.autograd.grad(out_mixed.sum(), mixed, create_graph=True)
+    norm = torch.sqrt((grad_mixed ** 2).sum(dim=(1, 2, 3)))
+    gp = ((norm - 1.0) ** 2).mean()
+    loss = loss_fake - loss_real + delta * gp
+    return loss, loss_real, loss_fake, gp, norm, grad_mixed
+
+
+def critic_grads(PD, PG, y2, x, z, ep, which, delta=10.0, nicg=1, dtype=torch.float32):
+    """Gradients of the critic loss w.r.t. the critic's trainable weights.
+    which='y2' -> GT:533-552 ; which='dem' -> GT:555-571.
+    inputs in the reference order [y2, x, z, ep].  Returns (outs[2], grads, aux)."""
+    TD = to_torch(PD, dtype, requires_grad=True)
+    TG = to_torch(PG, dtype)
+    y2_t, x_t, z_t, ep_t = _t(y2, dtype), _t(x, dtype), _t(z, dtype), _t(ep, dtype)
+    y1 = x_t[..., 0:1]                                           # GT:528-529
+    with torch.no_grad():
+        attr = g_forward_t(TG, x_t, z_t, nicg=nicg)              # GT:533 (no grad into G here)
+    if which == "y2":
+        real, fake = y2_t, y1 + attr                             # GT:534
+    else:
+        real, fake = y2_t - y1, attr                             # GT:530, 557
+    loss, lr_, lf_, gp, norm, gmix = _critic_loss_t(TD, real, fake, ep_t.reshape(-1, 1, 1, 1), delta)
+    names = trainable_names(PD)
+    gs = torch.autograd.grad(loss, [TD[n] for n in names], allow_unused=True)
+    grads = {n: (g.detach().numpy() if g is not None else np.zeros_like(PD[n])) for n, g in zip(names, gs)}
+    aux = dict(loss=float(loss.detach()), gp=float(gp.detach()), norm=norm.detach().numpy(),
+               grad_mixed=gmix.detach().numpy(), attr=attr.numpy())
+    return [float(lr_.detach()), float(lf_.detach())], grads, aux
+
+
+def _g_loss_t(TG, TDy2, TDdem, x_t, y2_t, z_t, thr, nicg):
+    """Generator loss, GT:574-592.  Returns the 6 reported scalars (torch)."""
+    y1 = x_t[..., 0:1]
+    real_dem = y2_t - y1                                         # GT:530
+    attr = g_forward_t(TG, x_t, z_t, nicg=nicg)                  # GT:533
+    fake_y2 = y1 + attr                                          # GT:534
+    loss_fake = d_forward_t(TDy2, fake_y2).mean()                # GT:541
+    loss_fake_dem = d_forward_t(TDdem, attr).mean()              # GT:560
+    m1 = (attr - real_dem).abs().mean() * 100.0                  # GT:576
+    wr = (y2_t >= thr).to(y2_t.dtype)                            # GT:581 (no gradient)
+    wf = (fake_y2.detach() >= thr).to(y2_t.dtype)                # GT:582 (no gradient)
+    inter = (wr * wf).sum()
+    dice = (2.0 * inter + 1e-7) / (wr.sum() + wf.sum() + 1e-7)   # GT:153-157
+    m4 = (1.0 - dice) * 1.0                                      # GT:583
+    m3 = ((wr.sum() / 1000.0 - wf.sum() / 1000.0) ** 2) * 100.0  # GT:587-589
+    loss = (-loss_fake) + (-loss_fake_dem) + m1 + m3 + m4        # GT:592
+    return loss, loss_fake, loss_fake_dem, m1, m3, m4
+
+
+def g_eval(PG, PDy2, PDdem, x, y2, z, thr=0.5, nicg=1, dtype=torch.float32):
+    """netG_no_update([x, y2, z]) -> 6 scalars.  GT:595-596."""
+    with torch.no_grad():
+        outs = _g_loss_t(to_torch(PG, dtype), to_torch(PDy2, dtype), to_torch(PDdem, dtype),
+                         _t(x, dtype), _t(y2, dtype), _t(z, dtype), thr, nicg)
+    return [float(o) for o in outs]
+
+
+def g_grads(PG, PDy2, PDdem, x, y2, z, thr=0.5, nicg=1, dtype=torch.float32):
+    """Gradient of the generator loss w.r.t. netG.trainable_weights.  GT:594."""
+    TG = to_torch(PG, dtype, requires_grad=True)
+    outs = _g_loss_t(TG, to_torch(PDy2, dtype), to_torch(PDdem, dtype),
+                     _t(x, dtype), _t(y2, dtype), _t(z, dtype), thr, nicg)
+    names = trainable_names(PG)
+    gs = torch.autograd.grad(outs[0], [TG[n] for n in names], allow_unused=True)
+    grads = {n: (g.detach().numpy() if g is not None else np.zeros_like(PG[n])) for n, g in zip(names, gs)}
+    return [float(o.detach()) for o in outs], grads
+
+
+# ----------------------------------------------------------------------------
+# The four closures as one stateful object (GT:549-598)
+# ----------------------------------------------------------------------------
+class OracleTrainers:
+    """netD_y2_train / netD_dem_train / netG_no_update / netG_train with the
+    reference's positional contracts; weights are NumPy dicts updated in place."""
+
+    def __init__(self, PG, PDy2, PDdem, lrD=1e-4, lrG=1e-4, delta=10.0, thr=0.5, nicg=1,
+                 dtype=torch.float32):
+        self.PG, self.PDy2, self.PDdem = PG, PDy2, PDdem
+        self.delta, self.thr, self.nicg, self.dtype = delta, thr, nicg, dtype
+        self.optD_y2 = KerasAdam(trainable_names(PDy2), lrD, 0.0, 0.9)   # GT:549
+        self.optD_dem = KerasAdam(trainable_names(PDdem), lrD, 0.0, 0.9)  # GT:568
+        self.optG = KerasAdam(trainable_names(PG), lrG, 0.0, 0.9)        # GT:594
+
+    def netD_y2_train(self, inputs):
+        y2, x, z, ep = inputs
+        outs, grads, _ = critic_grads(self.PDy2, self.PG, y2, x, z, ep, "y2", self.delta, self.nicg, self.dtype)
+        self.optD_y2.apply(self.PDy2, grads)
+        return outs
+
+    def netD_dem_train(self, inputs):
+        y2, x, z, ep = inputs
+        outs, grads, _ = critic_grads(self.PDdem, self.PG, y2, x, z, ep, "dem", self.delta, self.nicg, self.dtype)
+        self.optD_dem.apply(self.PDdem, grads)
+        return outs
+
+    def netG_no_update(self, inputs):
+        x, y2, z = inputs
+        return g_eval(self.PG, self.PDy2, self.PDdem, x, y2, z, self.thr, self.nicg, self.dtype)
+
+    def netG_train(self, inputs):
+        x, y2, z = inputs
+        outs, grads = g_grads(self.PG, self.PDy2, self.PDdem, x, y2, z, self.thr, self.nicg, self.dtype)
+        self.optG.apply(self.PG, grads)
+        return outs
+
+
+# ----------------------------------------------------------------------------
+# Synthetic inputs
+# ----------------------------------------------------------------------------
+def synth_batch(seed, B, H=256, W=256, nicg=1):
+    """Seeded synthetic (x, y2, z, ep): sparse blob maps in [0,1] inside an
+    elliptical 'brain' mask (mirrors GT:685-687, 715-716), z~N(0,1) (GT:807),
+    ep~U[0,1) (GT:808; both drawn in float64 then cast like the reference)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    cy, cx = (H - 1) / 2.0 + 0.5, (W - 1) / 2.0 + 0.5
+    mask = (((yy - cy) / (100.0 * H / 256)) ** 2 + ((xx - cx) / (80.0 * W / 256)) ** 2) <= 1.0
+    x0 = np.zeros((B, H, W), np.float64)
+    y2 = np.zeros((B, H, W), np.float64)
+    sc = H / 256.0
+    for b in range(B):
+        K = int(rng.integers(3, 9))
+        cys = cy + rng.uniform(-70, 70, K) * sc
+        cxs = cx + rng.uniform(-55, 55, K) * sc
+        amp = rng.uniform(0.3, 1.0, K)
+        sig = rng.uniform(2.0, 8.0, K) * sc
+        amp2 = amp * rng.uniform(0.7, 1.3, K)
+        sig2 = sig * rng.uniform(0.7, 1.3, K)
+        keep = rng.uniform(size=K) > 0.15
+        for k in range(K):
+            d2 = (yy - cys[k]) ** 2 + (xx - cxs[k]) ** 2
+            x0[b] += amp[k] * np.exp(-d2 / (2 * sig[k] ** 2))
+            if keep[k]:
+                y2[b] += amp2[k] * np.exp(-d2 / (2 * sig2[k] ** 2))
+        x0[b] = np.clip(x0[b] + 0.15 * rng.uniform(size=(H, W)) ** 4, 0, 1) * mask
+        y2[b] = np.clip(y2[b] + 0.15 * rng.uniform(size=(H, W)) ** 4, 0, 1) * mask
+    x = x0[..., None]
+    if nicg == 2:
+        fl = mask * (0.35 + 0.4 * x0 + 0.05 * rng.standard_normal((B, H, W)))
+        fl = (fl - fl.min()) / max(fl.max() - fl.min(), 1e-12)
+        x = np.stack([x0, fl], axis=-1)
+    z = rng.normal(size=(B, NOISE_SIZE, 1))
+    ep = rng.uniform(size=(B, 1, 1, 1))
+    return (x.astype(np.float32), y2[..., None].astype(np.float32),
+            z.astype(np.float32), ep.astype(np.float32))
