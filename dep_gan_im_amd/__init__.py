@@ -1,0 +1,11 @@
+"""dep_gan_im_amd -- MI355X-native DEP-GAN two-critic WGAN-GP train step.
+
+(The task names the package `dep-gan-im_amd`; hyphens are not importable, so the
+directory is `dep_gan_im_amd`.)  Hand-written HIP kernels for gfx950 behind the
+C ABI of include/depgan.h; this package is the Python host side that keeps the
+reference's Keras-style call surface.
+"""
+from ._lib import DepganError, load  # noqa: F401
+from .models import Dis_C2D_FCN1, Gen_UNet2D  # noqa: F401
+from .trainers import Trainers, build_trainers  # noqa: F401
+from .engine import Engine  # noqa: F401

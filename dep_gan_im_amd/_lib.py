@@ -1,0 +1,116 @@
+"""ctypes binding of libdepgan.so (the C ABI declared in include/depgan.h).
+
+There is no CPU fallback: if the HIP library is missing the import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdepgan.so")
+
+EXPORTS = [
+    "depgan_last_error", "depgan_create", "depgan_destroy", "depgan_set_stream", "depgan_param_count",
+    "depgan_param_info", "depgan_arena_floats", "depgan_arena_ptr", "depgan_weights_changed", "depgan_g_forward",
+    "depgan_d_forward", "depgan_critic_grads", "depgan_critic_step", "depgan_g_eval", "depgan_g_grads",
+    "depgan_g_step", "depgan_apply_adam", "depgan_last_sums", "depgan_profile_enable", "depgan_profile_read",
+    "depgan_profile_reset", "depgan_op_conv2d", "depgan_op_conv2d_bwd_data", "depgan_op_conv2d_wgrad",
+    "depgan_op_maxpool",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("batch", C.c_int), ("height", C.c_int), ("width", C.c_int), ("nicg", C.c_int),
+                ("first_fm", C.c_int), ("im_thresh", C.c_float), ("delta", C.c_float), ("lrD", C.c_float),
+                ("lrG", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float)]
+
+
+NET_G, NET_D_Y2, NET_D_DEM = 0, 1, 2
+ARENA_PARAMS, ARENA_NONTRAINABLE, ARENA_GRADS, ARENA_ADAM_M, ARENA_ADAM_V = range(5)
+
+_lib = None
+
+
+class DepganError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdepgan.so; raises if it has not been built (python -m dep_gan_im_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DepganError(
+            "libdepgan.so not found at %s -- the HIP library is the product; build it with "
+            "`python -m dep_gan_im_amd.build` (needs hipcc). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    fp, vp, ip = C.POINTER(C.c_float), C.c_void_p, C.POINTER(C.c_int)
+    lib.depgan_last_error.restype = C.c_char_p
+    lib.depgan_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.depgan_destroy.argtypes = [vp]
+    lib.depgan_destroy.restype = None
+    lib.depgan_set_stream.argtypes = [vp, vp]
+    lib.depgan_param_count.argtypes = [vp, C.c_int]
+    lib.depgan_param_info.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int, ip, ip, C.POINTER(C.c_long), ip]
+    lib.depgan_arena_floats.argtypes = [vp, C.c_int, C.c_int]
+    lib.depgan_arena_floats.restype = C.c_long
+    lib.depgan_arena_ptr.argtypes = [vp, C.c_int, C.c_int]
+    lib.depgan_arena_ptr.restype = vp
+    lib.depgan_weights_changed.argtypes = [vp, C.c_int]
+    lib.depgan_g_forward.argtypes = [vp, vp, vp, vp, C.c_int]
+    lib.depgan_d_forward.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    lib.depgan_critic_grads.argtypes = [vp, C.c_int, vp, vp, vp, vp, fp]
+    lib.depgan_critic_step.argtypes = [vp, C.c_int, vp, vp, vp, vp, fp]
+    lib.depgan_g_eval.argtypes = [vp, vp, vp, vp, fp]
+    lib.depgan_g_grads.argtypes = [vp, vp, vp, vp, fp]
+    lib.depgan_g_step.argtypes = [vp, vp, vp, vp, fp]
+    lib.depgan_apply_adam.argtypes = [vp, C.c_int]
+    lib.depgan_last_sums.argtypes = [vp, fp]
+    lib.depgan_profile_enable.argtypes = [vp, C.c_int]
+    lib.depgan_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]
+    lib.depgan_profile_reset.argtypes = [vp]
+    lib.depgan_op_conv2d.argtypes = [vp, vp, vp, vp] + [C.c_int] * 8 + [vp]
+    lib.depgan_op_conv2d_bwd_data.argtypes = [vp, vp, vp] + [C.c_int] * 7 + [vp]
+    lib.depgan_op_conv2d_wgrad.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp]
+    lib.depgan_op_maxpool.argtypes = [vp, vp] + [C.c_int] * 4 + [vp]
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().depgan_last_error()
+        raise DepganError("%s failed (status %d): %s" % (what or "libdepgan call", rc,
+                                                         msg.decode() if msg else "?"))
+
+
+_hip = None
+
+
+def hip():
+    """libamdhip64 for raw device copies (weights in/out of the C-side arenas)."""
+    global _hip
+    if _hip is None:
+        last = None
+        for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+            try:
+                _hip = C.CDLL(name)
+                break
+            except OSError as e:  # pragma: no cover
+                last = e
+        if _hip is None:
+            raise DepganError("cannot load libamdhip64: %s" % last)
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipDeviceSynchronize.argtypes = []
+    return _hip
+
+
+H2D, D2H, D2D = 1, 2, 3
+
+
+def memcpy(dst, src, nbytes, kind):
+    rc = hip().hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), C.c_int(kind))
+    if rc != 0:
+        raise DepganError("hipMemcpy failed with status %d" % rc)

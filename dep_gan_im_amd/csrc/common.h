@@ -1,0 +1,144 @@
+// Shared declarations for the DEP-GAN hot-path HIP library (gfx950 / MI355X).
+//
+// Data layout: every activation is NHWC fp32 with the channel dimension
+// contiguous; a TView carries (batch, row, pixel) strides in floats so one
+// kernel serves plain tensors, channel slices of a concat buffer (reference
+// concatenate() at GT:450/465/479 is never materialised twice) and the 2x
+// strided pixel grids of the 2x2/stride-2 transposed convolution (GT:308).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct TView {
+  float* p;
+  long sB, sY, sX;  // strides in floats; channel stride is 1
+};
+
+static inline TView make_view(float* p, int H, int W, int C) {
+  TView v;
+  v.p = p;
+  v.sX = C;
+  v.sY = (long)W * C;
+  v.sB = (long)H * W * C;
+  return v;
+}
+// channel slice [c0, ...) of a tensor with Ctot channels
+static inline TView make_view_slice(float* p, int H, int W, int Ctot, int c0) {
+  TView v = make_view(p, H, W, Ctot);
+  v.p = p + c0;
+  return v;
+}
+static inline TView null_view() {
+  TView v;
+  v.p = nullptr;
+  v.sB = v.sY = v.sX = 0;
+  return v;
+}
+
+// Fused epilogue description, applied in this order to acc (the raw contraction):
+//   v = acc + bias[co]
+//   v = v * scale[co] + shift[co]          (phase-0 BatchNorm affine)
+//   out_pre = v                            (pre-FiLM tensor kept for the G backward)
+//   v = v * film_mul[b,co] + film_add[b,co]  (GT:403-404)
+//   v = max(v, 0)                          (relu)
+//   v += res                               (residual add GT:407, or a gradient join)
+//   v *= (mask > 0)                        (ReLU mask of the consumer side in backward passes)
+//   out = accumulate ? out + v : v
+struct Epilogue {
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* film_mul;
+  const float* film_add;
+  int film_ld;  // row stride (floats) of film_mul / film_add
+  TView out_pre;
+  TView res;
+  TView mask;
+  int relu;
+  int accumulate;
+};
+
+struct ConvArgs {
+  TView in;
+  TView out;
+  const float* w;  // packed (igemm) or strided (direct) weights
+  int B, H, W, Cin, Cout;
+  Epilogue ep;
+  // direct kernel only: weight element (tap, ci, co) = w[tapidx*wsT + ci*wsI + co*wsO],
+  // tapidx = flip ? ntaps-1-tap : tap
+  long wsT, wsI, wsO;
+  int flip;
+};
+
+struct WgradArgs {
+  TView x;      // operand shifted by the tap ('same' padding)
+  TView dy;     // operand at the output pixel
+  float* part;  // [nchunks][ntaps][Cin][Cout] partial sums
+  int B, H, W, Cin, Cout;
+  int nTiles, tilesPerChunk;
+};
+
+#define DG_OK 0
+#define DG_ERR_ARG 1
+#define DG_ERR_HIP 2
+#define DG_ERR_UNSUPPORTED 3
+
+void dg_set_error(const char* fmt, ...);
+
+#define HIPCHECK(expr)                                                              \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      dg_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return DG_ERR_HIP;                                                            \
+    }                                                                               \
+  } while (0)
+
+#define DGCHECK(expr)          \
+  do {                         \
+    int _r = (expr);           \
+    if (_r != DG_OK) return _r; \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- conv plans -----------------------------------------------------------
+// How one convolution maps on the MFMA implicit-GEMM kernel.
+struct ConvPlan {
+  int KS, Cin, Cout;
+  int MF;    // MFMA tile edge: 32 (v_mfma_f32_32x32x2_f32) or 16 (v_mfma_f32_16x16x4_f32)
+  int NT;    // output channels per workgroup
+  int CK;    // input channels staged per LDS chunk
+  int nNT, nCC;
+  size_t packedFloats;
+  int variant;  // index into the instantiation table, -1 = not MFMA-eligible
+};
+ConvPlan dg_plan_conv(int KS, int Cin, int Cout);
+
+// weight packing: src is HWIO (io=0) or HWOI (io=1, Conv2DTranspose layout)
+// roles: if transpose==0 the GEMM K index is the source I axis and N the O axis
+// (forward conv); if transpose==1 K is the source O axis and N the I axis
+// (backward-data).  flip reverses the tap order.  kscale (optional) multiplies
+// by a per-K-channel factor (BN scale folded into backward-data weights).
+int dg_pack_weights(const ConvPlan& pl, const float* src, int srcI, int srcO, int io, int transpose, int flip,
+                    const float* kscale, float* dst, hipStream_t st);
+
+int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
+int dg_conv_direct(int KS, const ConvArgs& a, hipStream_t st);
+
+// wgrad: returns number of chunks used through *nchunks; part must hold
+// dg_wgrad_part_floats() floats.
+size_t dg_wgrad_part_floats(int KS, int B, int H, int W, int Cin, int Cout);
+int dg_wgrad(int KS, const WgradArgs& a, int* nchunks, hipStream_t st);
+// out[(tap,ci,co)] (+)= scale[co] * sum_chunks part ; raw (optional) gets the unscaled sum.
+// oi=1 writes [tap][co][ci] (Conv2DTranspose kernel layout) instead of [tap][ci][co].
+int dg_wgrad_reduce(const float* part, int nchunks, int ntaps, int Cin, int Cout, const float* scale, float* out,
+                    float* raw, int accumulate, int oi, hipStream_t st);
+
+// small-Cin wgrad (VALU), same slab format as dg_wgrad
+size_t dg_wgrad_small_part_floats(int KS, int B, int H, int W, int Cin, int Cout);
+int dg_wgrad_small(int KS, const WgradArgs& a, int* nchunks, hipStream_t st);

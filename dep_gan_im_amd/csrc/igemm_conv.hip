@@ -1,0 +1,324 @@
+// NHWC fp32 implicit-GEMM convolution on the CDNA4 fp32 matrix cores.
+//
+// Replaces the Keras Conv2D(padding='same', strides=1) calls of the reference
+// (GT:286, 294, 301; critic GT:319-338) and, with flipped / transposed packed
+// weights, their backward-data and the gradient-penalty "u-forward" passes
+// (SURVEY.md 8a rows A1, A2, A6).  No im2col buffer is materialised.
+//
+// Mapping (one workgroup = 256 threads = 4 waves, one wave per SIMD):
+//   M = 16x16 output pixels of one sample (each wave: 4 rows x 16 px = 64 px)
+//   N = NT output channels (NT = MF: one MFMA column tile per wave)
+//   K = taps x Cin, walked as  Cin-chunk (CK channels) -> tap -> 4 MFMAs / b128
+// LDS holds the (16+KS-1)^2 x CK input halo tile and the taps x NT x CK weight
+// panel; rows are padded by 4 floats (CKP = CK+4) so the 16-byte fragment
+// reads of the 32/16 pixel rows of one MFMA tile spread over the banks.
+// A-fragment lane (r, h) reads 4 consecutive channels [4h, 4h+4) of pixel r:
+// MFMA j of the group uses channel 4h+j on both operands, i.e. K is permuted
+// identically for A and B, which a contraction does not care about.
+// Global loads for stage s+1 are issued into registers before the MFMAs of
+// stage s and written to LDS after them (one register set, T14-style).
+#include "common.h"
+#include "epilogue.h"
+
+template <int MF>
+struct Mfma;
+template <>
+struct Mfma<32> {
+  typedef f32x16 acc_t;
+  static constexpr int NREG = 16;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
+};
+template <>
+struct Mfma<16> {
+  typedef f32x4 acc_t;
+  static constexpr int NREG = 4;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int j, int h) { return 4 * h + j; }
+};
+
+template <int MF, int KS, int CK, int TAPG>
+__global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
+  constexpr int NT = MF;
+  constexpr int PAD = KS / 2;
+  constexpr int TW = 16 + KS - 1;
+  constexpr int PIXT = TW * TW;
+  constexpr int CKP = CK + 4;
+  constexpr int NTAPS = KS * KS;
+  constexpr int NG = NTAPS / TAPG;
+  constexpr int KB = 256 / MF;  // channels covered by one 16-byte fragment read (4 MFMAs)
+  constexpr int NSUB = CK / KB;
+  constexpr int MT = 64 / MF;  // MFMA row tiles per wave
+  constexpr int XV = CK / 4;
+  constexpr int XTOT = PIXT * XV;
+  constexpr int XPIECES = (XTOT + 255) / 256;
+  constexpr int WTOT = TAPG * NT * XV;
+  constexpr int WPIECES = (WTOT + 255) / 256;
+  static_assert(NTAPS % TAPG == 0 && (TAPG == NTAPS || TAPG == KS), "tap grouping");
+  static_assert(CK % KB == 0, "chunk must hold whole fragment reads");
+  typedef typename Mfma<MF>::acc_t acc_t;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                // [PIXT][CKP]
+  float* ws = smem + PIXT * CKP;   // [TAPG][NT][CKP]
+
+  const int tid = threadIdx.x;
+  const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + 15) >> 4;
+  int t = blockIdx.x;
+  const int tx0 = (t % tilesX) * 16;
+  t /= tilesX;
+  const int ty0 = (t % tilesY) * 16;
+  const int b = t / tilesY;
+  const int n0 = blockIdx.y * NT;
+  const int nCC = (a.Cin + CK - 1) / CK;
+  const int NS = nCC * NG;
+  const float* inb = a.in.p + (long)b * a.in.sB;
+
+  f32x4 xr[XPIECES];
+  f32x4 wr[WPIECES];
+
+  auto prefetch = [&](int s) {
+    const int cc = s / NG, tg = s - cc * NG;
+    if (tg == 0) {
+#pragma unroll
+      for (int i = 0; i < XPIECES; ++i) {
+        const int q = tid + i * 256;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q < XTOT) {
+          const int pix = q / XV, part = q - pix * XV;
+          const int ly = pix / TW, lx = pix - ly * TW;
+          const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
+          const int c = cc * CK + part * 4;
+          if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin)
+            v = *reinterpret_cast<const f32x4*>(inb + (long)iy * a.in.sY + (long)ix * a.in.sX + c);
+        }
+        xr[i] = v;
+      }
+    }
+    const float* wsrc = a.w + ((size_t)((size_t)blockIdx.y * nCC + cc) * NTAPS + (size_t)tg * TAPG) * (NT * CK);
+#pragma unroll
+    for (int i = 0; i < WPIECES; ++i) {
+      const int q = tid + i * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q < WTOT) v = *reinterpret_cast<const f32x4*>(wsrc + (size_t)q * 4);
+      wr[i] = v;
+    }
+  };
+  auto commit = [&](int s) {
+    const int cc = s / NG, tg = s - cc * NG;
+    if (tg == 0) {
+#pragma unroll
+      for (int i = 0; i < XPIECES; ++i) {
+        const int q = tid + i * 256;
+        if (q < XTOT) {
+          const int pix = q / XV, part = q - pix * XV;
+          *reinterpret_cast<f32x4*>(xs + pix * CKP + part * 4) = xr[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WPIECES; ++i) {
+      const int q = tid + i * 256;
+      if (q < WTOT) {
+        const int row = q / XV, part = q - row * XV;
+        *reinterpret_cast<f32x4*>(ws + row * CKP + part * 4) = wr[i];
+      }
+    }
+  };
+
+  const int lane = tid & 63, wv = tid >> 6;
+  const int r = lane % MF, h = lane / MF;
+  int apix[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int py, px;
+    if (MF == 32) {
+      py = 4 * wv + 2 * mt + (r >> 4);
+      px = r & 15;
+    } else {
+      py = 4 * wv + mt;
+      px = r;
+    }
+    apix[mt] = (py * TW + px) * CKP + 4 * h;
+  }
+  const int boff = r * CKP + 4 * h;
+
+  acc_t acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < Mfma<MF>::NREG; ++j) acc[mt][j] = 0.f;
+
+  prefetch(0);
+  for (int s = 0; s < NS; ++s) {
+    __syncthreads();
+    commit(s);
+    __syncthreads();
+    if (s + 1 < NS) prefetch(s + 1);
+    const int tg = s % NG;
+#pragma unroll
+    for (int tl = 0; tl < TAPG; ++tl) {
+      const int tap = (TAPG == NTAPS) ? tl : (tg * TAPG + tl);
+      const int ty = tap / KS, tx = tap - ty * KS;
+      const int tapoff = (ty * TW + tx) * CKP;
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        f32x4 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(xs + apix[mt] + tapoff + sub * KB);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(ws + tl * (NT * CKP) + boff + sub * KB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = Mfma<MF>::run(av[mt][j], bv[j], acc[mt]);
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  const int co = n0 + r;
+  if (co < a.Cout) {
+    const EpiChan ch = epi_load_chan(a.ep, b, co, a.Cout);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int j = 0; j < Mfma<MF>::NREG; ++j) {
+        const int m = Mfma<MF>::row(j, h);
+        int py, px;
+        if (MF == 32) {
+          py = 4 * wv + 2 * mt + (m >> 4);
+          px = m & 15;
+        } else {
+          py = 4 * wv + mt;
+          px = m;
+        }
+        const int oy = ty0 + py, ox = tx0 + px;
+        if (oy < a.H && ox < a.W) epi_store(a, ch, b, oy, ox, co, acc[mt][j]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// variants
+// ---------------------------------------------------------------------------
+struct VariantInfo {
+  int MF, KS, CK, TAPG;
+};
+static const VariantInfo kVariants[] = {
+    {32, 3, 16, 9},   // 0
+    {16, 3, 16, 9},   // 1
+    {32, 5, 8, 25},   // 2
+    {16, 5, 16, 25},  // 3
+    {32, 1, 32, 1},   // 4
+    {16, 1, 16, 1},   // 5
+};
+
+ConvPlan dg_plan_conv(int KS, int Cin, int Cout) {
+  ConvPlan p;
+  p.KS = KS;
+  p.Cin = Cin;
+  p.Cout = Cout;
+  p.variant = -1;
+  p.MF = (Cout % 32 == 0) ? 32 : 16;
+  p.NT = p.MF;
+  p.CK = 16;
+  p.nNT = p.nCC = 0;
+  p.packedFloats = 0;
+  if (Cin < 8 || (Cin % 4) != 0 || Cout < 8) return p;  // direct kernel territory
+  for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i)
+    if (kVariants[i].MF == p.MF && kVariants[i].KS == KS) {
+      p.variant = i;
+      p.CK = kVariants[i].CK;
+    }
+  if (p.variant < 0) return p;
+  p.nNT = cdiv(Cout, p.NT);
+  p.nCC = cdiv(Cin, p.CK);
+  p.packedFloats = (size_t)p.nNT * p.nCC * KS * KS * p.NT * p.CK;
+  return p;
+}
+
+template <int MF, int KS, int CK, int TAPG>
+static int launch_variant(const ConvArgs& a, hipStream_t st) {
+  constexpr int TW = 16 + KS - 1;
+  constexpr size_t lds = (size_t)(TW * TW * (CK + 4) + TAPG * MF * (CK + 4)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_kernel<MF, KS, CK, TAPG>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(cdiv(a.W, 16) * cdiv(a.H, 16) * a.B), (unsigned)cdiv(a.Cout, MF));
+  hipLaunchKernelGGL((igemm_conv_kernel<MF, KS, CK, TAPG>), grid, dim3(256), lds, st, a);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a, hipStream_t st) {
+  if (pl.variant < 0) {
+    dg_set_error("dg_conv_igemm: no MFMA variant for KS=%d Cin=%d Cout=%d", pl.KS, pl.Cin, pl.Cout);
+    return DG_ERR_UNSUPPORTED;
+  }
+  if ((a.in.sX % 4) || (a.in.sY % 4) || (a.in.sB % 4) || (((uintptr_t)a.in.p) & 15)) {
+    dg_set_error("dg_conv_igemm: input view must be 16-byte aligned (strides %% 4 floats)");
+    return DG_ERR_ARG;
+  }
+  switch (pl.variant) {
+    case 0: return launch_variant<32, 3, 16, 9>(a, st);
+    case 1: return launch_variant<16, 3, 16, 9>(a, st);
+    case 2: return launch_variant<32, 5, 8, 25>(a, st);
+    case 3: return launch_variant<16, 5, 16, 25>(a, st);
+    case 4: return launch_variant<32, 1, 32, 1>(a, st);
+    case 5: return launch_variant<16, 1, 16, 1>(a, st);
+  }
+  return DG_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------
+// weight packing:  dst[nt][cc][tap][n][k]
+// ---------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int ntaps, int srcI,
+                                    int srcO, int io, int transpose, int flip, const float* __restrict__ kscale,
+                                    int NT, int CK, int nCC, int Kdim, int Ndim, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t q = i;
+    const int k = (int)(q % CK);
+    q /= CK;
+    const int n = (int)(q % NT);
+    q /= NT;
+    const int tap = (int)(q % ntaps);
+    q /= ntaps;
+    const int cc = (int)(q % nCC);
+    const int nt = (int)(q / nCC);
+    const int kk = cc * CK + k, nn = nt * NT + n;
+    float v = 0.f;
+    if (kk < Kdim && nn < Ndim) {
+      const int ci = transpose ? nn : kk;  // source I-axis index
+      const int co = transpose ? kk : nn;  // source O-axis index
+      const int ts = flip ? (ntaps - 1 - tap) : tap;
+      const size_t off = (size_t)ts * srcI * srcO + (io ? ((size_t)co * srcI + ci) : ((size_t)ci * srcO + co));
+      v = src[off];
+      if (kscale) v *= kscale[kk];
+    }
+    dst[i] = v;
+  }
+}
+
+int dg_pack_weights(const ConvPlan& pl, const float* src, int srcI, int srcO, int io, int transpose, int flip,
+                    const float* kscale, float* dst, hipStream_t st) {
+  const int Kdim = transpose ? srcO : srcI, Ndim = transpose ? srcI : srcO;
+  if (Kdim != pl.Cin || Ndim != pl.Cout) {
+    dg_set_error("dg_pack_weights: plan (%d->%d) does not match source roles (%d->%d)", pl.Cin, pl.Cout, Kdim, Ndim);
+    return DG_ERR_ARG;
+  }
+  const size_t total = pl.packedFloats;
+  const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, st, src, dst, pl.KS * pl.KS, srcI, srcO, io,
+                     transpose, flip, kscale, pl.NT, pl.CK, pl.nCC, Kdim, Ndim, total);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}

@@ -1,0 +1,137 @@
+// Host-side model state for the DEP-GAN hot path: parameter arenas, layer
+// tables (GT:316-345, GT:349-498), activation storage and the step drivers.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/depgan.h"
+#include "common.h"
+#include "noise.h"
+#include "ops.h"
+
+struct PInfo {
+  std::string name;
+  int shape[4];
+  int ndim;
+  size_t off, size;
+  bool trainable;
+};
+
+struct Net {
+  std::vector<PInfo> params;
+  std::map<std::string, int> index;
+  size_t nTrain = 0, nNon = 0;
+  float *P = nullptr, *NT = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
+  long adam_t = 0;
+  float lr = 1e-4f;
+  void add(const std::string& name, std::vector<int> shape, bool trainable);
+  float* p(const std::string& name) const;   // parameter pointer (either arena)
+  float* g(const std::string& name) const;   // gradient pointer (trainable only)
+};
+
+struct Tn {  // dense NHWC tensor
+  float* p = nullptr;
+  int H = 0, W = 0, C = 0;
+  TView view() const { return make_view(p, H, W, C); }
+  TView slice(int c0) const { return make_view_slice(p, H, W, C, c0); }
+  size_t per_sample() const { return (size_t)H * W * C; }
+};
+
+enum GKind { G_CONV, G_FILM, G_POOL, G_DECONV, G_HEAD };
+
+struct GLayer {
+  GKind kind;
+  std::string name;
+  int Cin = 0, Cout = 0;
+  int H = 0, W = 0;      // spatial size of the layer INPUT
+  // parameters
+  float *Wt = nullptr, *b = nullptr, *gamma = nullptr, *beta = nullptr, *mean = nullptr, *var = nullptr;
+  float *dW = nullptr, *db = nullptr, *dgamma = nullptr, *dbeta = nullptr;
+  float *s = nullptr, *t = nullptr, *rstd = nullptr;
+  // packed weights (deconv: one per tap)
+  ConvPlan pf, pb;
+  float* wpf[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* wpb[4] = {nullptr, nullptr, nullptr, nullptr};
+  // FiLM
+  int col_mul = -1, col_add = -1;
+  // tensors
+  TView in, out;           // forward views (in has Cin channels, out has Cout)
+  TView din, dout;         // gradient views (dout = grad wrt out, after the producer's mask)
+  TView in_mask;           // mask applied when writing din (null: none)
+  Tn u;                    // FiLM pre-activation (kept when training G)
+  int skip_of = -1;        // pool: index of the conv layer whose output is pooled
+  TView pool_dsrc;         // pool: gradient wrt the pooled tensor (raw)
+  TView pool_skipgrad;     // pool: gradient arriving through the concat
+  TView pool_dst;          // pool: masked gradient of the pooled conv's output
+};
+
+struct DLayer {
+  std::string name;
+  int KS, Cin, Cout, H, W;  // H, W: spatial size at this layer
+  bool pool;
+  ConvPlan pf, pb;
+};
+
+struct DNet {
+  Net net;
+  float* wpf[11];
+  float* wpb[11];
+  float *W[11], *b[11], *dW[11], *db[11];
+  float *w9, *b9, *wd, *bd, *dw9, *db9, *dwd, *dbd;
+};
+
+struct ProfRec {
+  hipEvent_t a, b;
+  int klass;
+  double flops;
+};
+
+struct depgan_ctx {
+  depgan_config cfg;
+  hipStream_t st = nullptr;
+  std::vector<void*> allocs;
+
+  // ---- generator ----
+  Net g;
+  std::vector<GLayer> gl;
+  NoiseParams np;
+  NoiseGrads ng;
+  NoiseActs na;
+  float* derived = nullptr;       // BN affines
+  float* heads_mean = nullptr;    // concatenated moving means of the head BNs
+  float* dheads = nullptr;        // [B][1024]
+  Tn attr;                        // generator output (B,H,W,1)
+  Tn du_tmp;                      // FiLM dU scratch (largest FiLM tensor)
+  float* dpre = nullptr;          // [B*H*W]
+  float* zbuf = nullptr;          // [B][32]
+
+  // ---- critics ----
+  DNet d[2];
+  std::vector<DLayer> dl;
+  int NB3 = 0;                     // 3*B
+  float* d_in = nullptr;           // [3B][H][W][1]
+  Tn d_act[11];                    // post-ReLU activations [3B]
+  Tn d_pool[11];                   // pooled outputs (pool layers only)
+  Tn d_dz[11];                     // gradient at the conv output (after ReLU mask)
+  Tn d_dpool[11];                  // gradient wrt pooled tensor (raw)
+  Tn d_ufull;                      // u-forward scratch for pooled layers [B]
+  float *d_t9 = nullptr, *d_out = nullptr;  // [3B][hw], [3B]
+  float* g0 = nullptr;             // [2B][H][W][1] image gradients
+  float* coefs = nullptr;          // [4] per-group upstream coefficients
+  float *norms = nullptr, *gp = nullptr;
+
+  // ---- shared scratch ----
+  float* part = nullptr;           // wgrad slabs
+  size_t partFloats = 0;
+  float* raw = nullptr;            // dWraw scratch (largest kernel)
+  float* Sraw = nullptr;           // [256] raw column sums
+  float* scratch = nullptr;        // reductions
+  float* scal = nullptr;           // device scalars
+  float* fake_y2 = nullptr;        // [B*H*W]
+  float last_sums[8];
+
+  // ---- profiling ----
+  bool prof_on = false;
+  std::vector<ProfRec> recs;
+};

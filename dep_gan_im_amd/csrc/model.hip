@@ -1,0 +1,1185 @@
+// Step drivers of the DEP-GAN hot path: Gen_UNet2D / Dis_C2D_FCN1 forward
+// (GT:316-498), the WGAN-GP critic update with its hand-derived double
+// backward (GT:533-571), the generator evaluation and
+// update (GT:574-598; A7-A9) and Keras Adam (A10).  The algebra follows
+// oracle/manual.py step for step.
+#include "model.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[1024] = "";
+void dg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* dg_get_error() { return g_err; }
+
+// ---------------------------------------------------------------------------
+// Net
+// ---------------------------------------------------------------------------
+void Net::add(const std::string& name, std::vector<int> shape, bool trainable) {
+  PInfo pi;
+  pi.name = name;
+  pi.ndim = (int)shape.size();
+  pi.size = 1;
+  for (int i = 0; i < 4; ++i) {
+    pi.shape[i] = i < pi.ndim ? shape[i] : 1;
+    pi.size *= pi.shape[i];
+  }
+  pi.trainable = trainable;
+  pi.off = trainable ? nTrain : nNon;
+  // keep every tensor 16-byte aligned inside its arena
+  const size_t padded = (pi.size + 3) & ~(size_t)3;
+  if (trainable) nTrain += padded; else nNon += padded;
+  index[name] = (int)params.size();
+  params.push_back(pi);
+}
+float* Net::p(const std::string& name) const {
+  const PInfo& pi = params[index.at(name)];
+  return (pi.trainable ? P : NT) + pi.off;
+}
+float* Net::g(const std::string& name) const {
+  const PInfo& pi = params[index.at(name)];
+  return G + pi.off;
+}
+
+static int dmalloc(depgan_ctx* c, float** p, size_t floats) {
+  void* q = nullptr;
+  if (floats == 0) floats = 4;
+  HIPCHECK(hipMalloc(&q, floats * sizeof(float)));
+  HIPCHECK(hipMemset(q, 0, floats * sizeof(float)));
+  c->allocs.push_back(q);
+  *p = (float*)q;
+  return DG_OK;
+}
+static int talloc(depgan_ctx* c, Tn* t, int N, int H, int W, int C) {
+  t->H = H;
+  t->W = W;
+  t->C = C;
+  return dmalloc(c, &t->p, (size_t)N * H * W * C);
+}
+static int net_alloc(depgan_ctx* c, Net* n) {
+  DGCHECK(dmalloc(c, &n->P, n->nTrain));
+  DGCHECK(dmalloc(c, &n->G, n->nTrain));
+  DGCHECK(dmalloc(c, &n->M, n->nTrain));
+  DGCHECK(dmalloc(c, &n->V, n->nTrain));
+  DGCHECK(dmalloc(c, &n->NT, n->nNon));
+  return DG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// profiling helpers
+// ---------------------------------------------------------------------------
+struct ProfScope {
+  depgan_ctx* c;
+  bool live;
+  ProfScope(depgan_ctx* c_, int klass, double flops) : c(c_), live(c_->prof_on) {
+    if (!live) return;
+    ProfRec r;
+    r.klass = klass;
+    r.flops = flops;
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+    hipEventRecord(r.a, c->st);
+    c->recs.push_back(r);
+  }
+  ~ProfScope() {
+    if (live) hipEventRecord(c->recs.back().b, c->st);
+  }
+};
+
+static int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
+  const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cin * a.Cout * KS * KS;
+  if (pl.variant >= 0) {
+    ProfScope ps(c, 0, fl);
+    return dg_conv_igemm(pl, a, c->st);
+  }
+  ProfScope ps(c, 2, fl);
+  return dg_conv_direct(KS, a, c->st);
+}
+
+static void zero_ep(Epilogue* e) {
+  memset(e, 0, sizeof(*e));
+  e->out_pre = e->res = e->mask = null_view();
+}
+
+static TView view_offset(TView v, long samples) {
+  v.p += samples * v.sB;
+  return v;
+}
+static TView strided2(TView v, int di, int dj) {  // pixel grid (2i+di, 2j+dj)
+  TView r = v;
+  r.p = v.p + di * v.sY + dj * v.sX;
+  r.sY = 2 * v.sY;
+  r.sX = 2 * v.sX;
+  return r;
+}
+
+// weight gradient: slabs + reduction (+ optional BN scale / raw copy / OI layout)
+static int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, int Cin, int Cout,
+                      const float* scale, float* out, float* raw, int accumulate, int oi) {
+  WgradArgs a;
+  a.x = x;
+  a.dy = dy;
+  a.part = c->part;
+  a.B = N;
+  a.H = H;
+  a.W = W;
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.nTiles = a.tilesPerChunk = 0;
+  int nch = 0;
+  const double fl = 2.0 * N * H * W * (double)Cin * Cout * KS * KS;
+  if (Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 8) {
+    if (dg_wgrad_part_floats(KS, N, H, W, Cin, Cout) > c->partFloats) {
+      dg_set_error("wgrad slab workspace too small");
+      return DG_ERR_ARG;
+    }
+    ProfScope ps(c, 1, fl);
+    DGCHECK(dg_wgrad(KS, a, &nch, c->st));
+  } else {
+    if (dg_wgrad_small_part_floats(KS, N, H, W, Cin, Cout) > c->partFloats) {
+      dg_set_error("wgrad slab workspace too small");
+      return DG_ERR_ARG;
+    }
+    ProfScope ps(c, 2, fl);
+    DGCHECK(dg_wgrad_small(KS, a, &nch, c->st));
+  }
+  ProfScope ps(c, 2, 0.0);
+  return dg_wgrad_reduce(c->part, nch, KS * KS, Cin, Cout, scale, out, raw, accumulate, oi, c->st);
+}
+
+// ---------------------------------------------------------------------------
+// generator construction (GT:349-498)
+// ---------------------------------------------------------------------------
+static const char* kHeadSfx[NOISE_NHEADS] = {"add_m3", "mul_m3", "add_m2", "mul_m2", "add_m1", "mul_m1", "add",
+                                             "mul",    "add_p3", "mul_p3", "add_p2", "mul_p2", "add_p1", "mul_p1"};
+static const int kHeadMult[NOISE_NHEADS] = {3, 3, 2, 2, 1, 1, 4, 4, 3, 3, 2, 2, 1, 1};
+
+struct TrunkEnt {
+  GKind kind;
+  const char* name;
+  int ci, co;       // in units of first_fm (ci = -1: nicg; co = -1: 1 output channel)
+  const char* aux;  // film key / skip name
+};
+static const TrunkEnt kTrunk[] = {
+    {G_CONV, "gen_0", -1, 1, ""},        {G_FILM, "gen_noise_m1", 1, 1, "m1"}, {G_CONV, "gen_1", 1, 1, ""},
+    {G_POOL, "skip1", 0, 0, ""},         {G_CONV, "gen_2", 1, 2, ""},          {G_FILM, "gen_noise_m2", 2, 2, "m2"},
+    {G_CONV, "gen_3", 2, 2, ""},         {G_POOL, "skip2", 0, 0, ""},          {G_CONV, "gen_4", 2, 3, ""},
+    {G_FILM, "gen_noise_m3", 3, 3, "m3"}, {G_CONV, "gen_5", 3, 3, ""},         {G_POOL, "skip3", 0, 0, ""},
+    {G_CONV, "gen_8", 3, 4, ""},         {G_FILM, "gen_noise_p4", 4, 4, ""},   {G_CONV, "gen_9", 4, 4, ""},
+    {G_DECONV, "de_gen_9", 4, 4, "skip3"}, {G_CONV, "gen_10", 7, 3, ""},       {G_FILM, "gen_noise_p3", 3, 3, "p3"},
+    {G_CONV, "gen_11", 3, 3, ""},        {G_DECONV, "de_gen_11", 3, 3, "skip2"}, {G_CONV, "gen_14", 5, 2, ""},
+    {G_FILM, "gen_noise_p2", 2, 2, "p2"}, {G_CONV, "gen_15", 2, 2, ""},        {G_DECONV, "de_gen_15", 2, 2, "skip1"},
+    {G_CONV, "gen_16", 3, 1, ""},        {G_FILM, "gen_noise_p1", 1, 1, "p1"}, {G_CONV, "gen_17", 1, 1, ""},
+    {G_HEAD, "gen_segmentation", 1, -1, ""},
+};
+static const int kNTrunk = sizeof(kTrunk) / sizeof(kTrunk[0]);
+
+static void add_bn(Net& n, const std::string& nm, int c) {
+  n.add(nm + "/gamma", {c}, true);
+  n.add(nm + "/beta", {c}, true);
+  n.add(nm + "/moving_mean", {c}, false);
+  n.add(nm + "/moving_variance", {c}, false);
+}
+
+static int build_generator(depgan_ctx* c) {
+  const int fm = c->cfg.first_fm, B = c->cfg.batch, H0 = c->cfg.height, W0 = c->cfg.width;
+  Net& g = c->g;
+  auto dense = [&](const std::string& nm, int fin, int fout) {
+    g.add("dense_" + nm + "/kernel", {fin, fout}, true);
+    g.add("dense_" + nm + "/bias", {fout}, true);
+    add_bn(g, "dense_bn_" + nm, fout);
+  };
+  dense("noise_1_add_f0", 1, fm);
+  dense("noise_1_add_f1", fm, fm);
+  for (int h = 0; h < NOISE_NHEADS; ++h) dense(std::string("noise_2_") + kHeadSfx[h], 32 * fm, fm * kHeadMult[h]);
+  size_t bnch = 2 * fm + 32 * fm;  // BN channels so far
+  for (int i = 0; i < kNTrunk; ++i) {
+    const TrunkEnt& e = kTrunk[i];
+    const int ci = e.ci < 0 ? c->cfg.nicg : e.ci * fm, co = e.co < 0 ? 1 : e.co * fm;
+    if (e.kind == G_CONV || e.kind == G_FILM) {
+      g.add(std::string("conv2d_") + e.name + "/kernel", {3, 3, ci, co}, true);
+      g.add(std::string("conv2d_") + e.name + "/bias", {co}, true);
+      add_bn(g, std::string("bn_") + e.name, co);
+      bnch += co;
+    } else if (e.kind == G_DECONV) {
+      g.add(std::string("deconv2d_") + e.name + "/kernel", {2, 2, co, ci}, true);
+      g.add(std::string("deconv2d_") + e.name + "/bias", {co}, true);
+      add_bn(g, std::string("bn_") + e.name, co);
+      bnch += co;
+    } else if (e.kind == G_HEAD) {
+      g.add(std::string(e.name) + "/kernel", {1, 1, ci, co}, true);
+      g.add(std::string(e.name) + "/bias", {co}, true);
+    }
+  }
+  g.lr = c->cfg.lrG;
+  DGCHECK(net_alloc(c, &g));
+  DGCHECK(dmalloc(c, &c->derived, 3 * bnch + 64));
+  DGCHECK(dmalloc(c, &c->heads_mean, 1024));
+  float* dv = c->derived;
+  auto take = [&](int n) {
+    float* r = dv;
+    dv += (n + 3) & ~3;
+    return r;
+  };
+
+  // ---- noise MLP pointers ----
+  if (fm != 32) {
+    dg_set_error("first_fm must be 32 (noise MLP kernels are sized for 32x32)");
+    return DG_ERR_UNSUPPORTED;
+  }
+  NoiseParams& np = c->np;
+  NoiseGrads& ng = c->ng;
+  np.W0 = g.p("dense_noise_1_add_f0/kernel");
+  np.b0 = g.p("dense_noise_1_add_f0/bias");
+  np.mean0 = g.p("dense_bn_noise_1_add_f0/moving_mean");
+  np.s0 = take(32); np.t0 = take(32); np.rstd0 = take(32);
+  np.W1 = g.p("dense_noise_1_add_f1/kernel");
+  np.b1 = g.p("dense_noise_1_add_f1/bias");
+  np.mean1 = g.p("dense_bn_noise_1_add_f1/moving_mean");
+  np.s1 = take(32); np.t1 = take(32); np.rstd1 = take(32);
+  np.sh = take(1024); np.th = take(1024); np.rstdh = take(1024);
+  np.meanh = c->heads_mean;
+  ng.dW0 = g.g("dense_noise_1_add_f0/kernel"); ng.db0 = g.g("dense_noise_1_add_f0/bias");
+  ng.dgamma0 = g.g("dense_bn_noise_1_add_f0/gamma"); ng.dbeta0 = g.g("dense_bn_noise_1_add_f0/beta");
+  ng.dW1 = g.g("dense_noise_1_add_f1/kernel"); ng.db1 = g.g("dense_noise_1_add_f1/bias");
+  ng.dgamma1 = g.g("dense_bn_noise_1_add_f1/gamma"); ng.dbeta1 = g.g("dense_bn_noise_1_add_f1/beta");
+  int col = 0;
+  std::map<std::string, int> headcol;
+  for (int h = 0; h < NOISE_NHEADS; ++h) {
+    const std::string nm = std::string("noise_2_") + kHeadSfx[h];
+    np.Wh[h] = g.p("dense_" + nm + "/kernel");
+    np.bh[h] = g.p("dense_" + nm + "/bias");
+    np.col0[h] = col;
+    np.ncol[h] = fm * kHeadMult[h];
+    ng.dWh[h] = g.g("dense_" + nm + "/kernel");
+    ng.dbh[h] = g.g("dense_" + nm + "/bias");
+    ng.dgamma_h[h] = g.g("dense_bn_" + nm + "/gamma");
+    ng.dbeta_h[h] = g.g("dense_bn_" + nm + "/beta");
+    headcol[nm] = col;
+    col += np.ncol[h];
+  }
+  DGCHECK(dmalloc(c, &c->na.h0, (size_t)B * 1024));
+  DGCHECK(dmalloc(c, &c->na.a0, (size_t)B * 1024));
+  DGCHECK(dmalloc(c, &c->na.h1, (size_t)B * 1024));
+  DGCHECK(dmalloc(c, &c->na.a1, (size_t)B * 1024));
+  DGCHECK(dmalloc(c, &c->na.lin, (size_t)B * 1024));
+  DGCHECK(dmalloc(c, &c->na.heads, (size_t)B * 1024));
+  DGCHECK(dmalloc(c, &c->dheads, (size_t)B * 1024));
+  DGCHECK(dmalloc(c, &c->zbuf, (size_t)B * 32));
+
+  // ---- trunk tensors ----
+  struct Cat {
+    Tn fwd, grad;
+    int co_deconv;
+  };
+  std::map<std::string, Cat> cats;
+  for (int i = 0; i < kNTrunk; ++i)
+    if (kTrunk[i].kind == G_DECONV) cats[kTrunk[i].aux].co_deconv = kTrunk[i].co * fm;
+
+  c->gl.resize(kNTrunk);
+  int H = H0, W = W0;
+  TView cur = null_view();
+  int producer = -1;  // index of the layer that produced `cur`
+  size_t maxFilm = 0;
+  for (int i = 0; i < kNTrunk; ++i) {
+    const TrunkEnt& e = kTrunk[i];
+    GLayer& L = c->gl[i];
+    L.kind = e.kind;
+    L.name = e.name;
+    L.Cin = e.ci < 0 ? c->cfg.nicg : e.ci * fm;
+    L.Cout = e.co < 0 ? 1 : e.co * fm;
+    L.H = H;
+    L.W = W;
+    L.in = cur;
+    L.din = L.dout = L.in_mask = null_view();
+    // where the gradient wrt this layer's input goes
+    if (producer >= 0) {
+      const GLayer& Pd = c->gl[producer];
+      if (Pd.kind == G_CONV) { L.din = Pd.dout; L.in_mask = Pd.out; }
+      else if (Pd.kind == G_FILM) { L.din = Pd.dout; }
+      else if (Pd.kind == G_POOL) { L.din = Pd.pool_dsrc; }
+      else if (Pd.kind == G_DECONV) {
+        Cat& ct = cats[kTrunk[producer].aux];
+        L.din = ct.grad.view();
+        L.in_mask = ct.fwd.view();
+      }
+    }
+    if (e.kind == G_CONV || e.kind == G_FILM || e.kind == G_DECONV) {
+      const std::string pre = (e.kind == G_DECONV) ? "deconv2d_" : "conv2d_";
+      L.Wt = g.p(pre + e.name + "/kernel"); L.b = g.p(pre + e.name + "/bias");
+      L.dW = g.g(pre + e.name + "/kernel"); L.db = g.g(pre + e.name + "/bias");
+      const std::string bn = std::string("bn_") + e.name;
+      L.gamma = g.p(bn + "/gamma"); L.beta = g.p(bn + "/beta");
+      L.mean = g.p(bn + "/moving_mean"); L.var = g.p(bn + "/moving_variance");
+      L.dgamma = g.g(bn + "/gamma"); L.dbeta = g.g(bn + "/beta");
+      L.s = take(L.Cout); L.t = take(L.Cout); L.rstd = take(L.Cout);
+    }
+    if (e.kind == G_CONV) {
+      L.pf = dg_plan_conv(3, L.Cin, L.Cout);
+      L.pb = dg_plan_conv(3, L.Cout, L.Cin);
+      if (L.pf.variant >= 0) DGCHECK(dmalloc(c, &L.wpf[0], L.pf.packedFloats));
+      if (i > 0 && L.pb.variant >= 0) DGCHECK(dmalloc(c, &L.wpb[0], L.pb.packedFloats));
+      const bool skip = (i + 1 < kNTrunk && kTrunk[i + 1].kind == G_POOL);
+      if (skip) {
+        Cat& ct = cats[kTrunk[i + 1].name];
+        DGCHECK(talloc(c, &ct.fwd, B, H, W, ct.co_deconv + L.Cout));
+        DGCHECK(talloc(c, &ct.grad, B, H, W, ct.co_deconv + L.Cout));
+        L.out = ct.fwd.slice(ct.co_deconv);
+        Tn dsk;
+        DGCHECK(talloc(c, &dsk, B, H, W, L.Cout));
+        L.dout = dsk.view();
+      } else {
+        Tn a, d;
+        DGCHECK(talloc(c, &a, B, H, W, L.Cout));
+        DGCHECK(talloc(c, &d, B, H, W, L.Cout));
+        L.out = a.view();
+        L.dout = d.view();
+      }
+      cur = L.out;
+    } else if (e.kind == G_FILM) {
+      L.pf = dg_plan_conv(3, L.Cin, L.Cout);
+      L.pb = dg_plan_conv(3, L.Cout, L.Cin);
+      DGCHECK(dmalloc(c, &L.wpf[0], L.pf.packedFloats));
+      DGCHECK(dmalloc(c, &L.wpb[0], L.pb.packedFloats));
+      const std::string key = e.aux;
+      const std::string sfx = key.empty() ? "" : ("_" + key);
+      L.col_mul = headcol["noise_2_mul" + sfx];
+      L.col_add = headcol["noise_2_add" + sfx];
+      Tn r, d;
+      DGCHECK(talloc(c, &r, B, H, W, L.Cout));
+      DGCHECK(talloc(c, &d, B, H, W, L.Cout));
+      DGCHECK(talloc(c, &L.u, B, H, W, L.Cout));
+      L.out = r.view();
+      L.dout = d.view();
+      if (r.per_sample() > maxFilm) maxFilm = r.per_sample();
+      cur = L.out;
+    } else if (e.kind == G_POOL) {
+      const GLayer& Pc = c->gl[i - 1];
+      Cat& ct = cats[e.name];
+      Tn p, dp;
+      DGCHECK(talloc(c, &p, B, H / 2, W / 2, Pc.Cout));
+      DGCHECK(talloc(c, &dp, B, H / 2, W / 2, Pc.Cout));
+      L.Cin = L.Cout = Pc.Cout;
+      L.skip_of = i - 1;
+      L.out = p.view();
+      L.pool_dsrc = dp.view();
+      L.pool_skipgrad = ct.grad.slice(ct.co_deconv);
+      L.pool_dst = Pc.dout;
+      H /= 2;
+      W /= 2;
+      cur = L.out;
+    } else if (e.kind == G_DECONV) {
+      L.pf = dg_plan_conv(1, L.Cin, L.Cout);
+      L.pb = dg_plan_conv(1, L.Cout, L.Cin);
+      for (int t = 0; t < 4; ++t) {
+        DGCHECK(dmalloc(c, &L.wpf[t], L.pf.packedFloats));
+        DGCHECK(dmalloc(c, &L.wpb[t], L.pb.packedFloats));
+      }
+      Cat& ct = cats[e.aux];
+      L.out = ct.fwd.slice(0);    // (2H, 2W) grid, first Cout channels
+      L.dout = ct.grad.slice(0);
+      H *= 2;
+      W *= 2;
+      cur = ct.fwd.view();
+    } else if (e.kind == G_HEAD) {
+      L.Wt = g.p(std::string(e.name) + "/kernel"); L.b = g.p(std::string(e.name) + "/bias");
+      L.dW = g.g(std::string(e.name) + "/kernel"); L.db = g.g(std::string(e.name) + "/bias");
+      DGCHECK(talloc(c, &c->attr, B, H, W, 1));
+      L.out = c->attr.view();
+    }
+    producer = i;
+  }
+  DGCHECK(dmalloc(c, &c->du_tmp.p, (size_t)B * maxFilm));
+  DGCHECK(dmalloc(c, &c->dpre, (size_t)B * H0 * W0));
+  DGCHECK(dmalloc(c, &c->fake_y2, (size_t)B * H0 * W0));
+  return DG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// critic construction (GT:316-345)
+// ---------------------------------------------------------------------------
+struct DEnt {
+  const char* name;
+  int k, ci, co;
+  bool pool;
+};
+static const DEnt kDis[11] = {
+    {"dis_0a", 5, 1, 16, false}, {"dis_0b", 5, 16, 16, true},  {"dis_1a", 5, 16, 32, false}, {"dis_1b", 5, 32, 32, true},
+    {"dis_2", 3, 32, 64, false}, {"dis_3", 3, 64, 64, true},   {"dis_4", 3, 64, 128, false}, {"dis_5", 3, 128, 128, true},
+    {"dis_6", 3, 128, 256, false}, {"dis_7", 3, 256, 256, false}, {"dis_8", 3, 256, 256, false},
+};
+
+static int build_critics(depgan_ctx* c) {
+  const int B = c->cfg.batch, H0 = c->cfg.height, W0 = c->cfg.width;
+  c->NB3 = 3 * B;
+  c->dl.resize(11);
+  int H = H0, W = W0;
+  for (int l = 0; l < 11; ++l) {
+    DLayer& L = c->dl[l];
+    L.name = kDis[l].name;
+    L.KS = kDis[l].k;
+    L.Cin = kDis[l].ci;
+    L.Cout = kDis[l].co;
+    L.pool = kDis[l].pool;
+    L.H = H;
+    L.W = W;
+    L.pf = dg_plan_conv(L.KS, L.Cin, L.Cout);
+    L.pb = dg_plan_conv(L.KS, L.Cout, L.Cin);
+    DGCHECK(talloc(c, &c->d_act[l], c->NB3, H, W, L.Cout));
+    DGCHECK(talloc(c, &c->d_dz[l], c->NB3, H, W, L.Cout));
+    if (L.pool) {
+      DGCHECK(talloc(c, &c->d_pool[l], c->NB3, H / 2, W / 2, L.Cout));
+      DGCHECK(talloc(c, &c->d_dpool[l], c->NB3, H / 2, W / 2, L.Cout));
+      H /= 2;
+      W /= 2;
+    }
+  }
+  const int HW = H * W;
+  // largest pooled-layer output (dis_0b at full resolution) bounds the u-forward scratch
+  DGCHECK(talloc(c, &c->d_ufull, B, H0, W0, 16));
+  DGCHECK(dmalloc(c, &c->d_in, (size_t)c->NB3 * H0 * W0));
+  DGCHECK(dmalloc(c, &c->d_t9, (size_t)c->NB3 * HW));
+  DGCHECK(dmalloc(c, &c->d_out, (size_t)c->NB3));
+  DGCHECK(dmalloc(c, &c->g0, (size_t)2 * B * H0 * W0));
+  DGCHECK(dmalloc(c, &c->coefs, 8));
+  DGCHECK(dmalloc(c, &c->norms, (size_t)B));
+  DGCHECK(dmalloc(c, &c->gp, 4));
+  const float hc[4] = {-1.0f / B, 1.0f / B, 1.0f, 1.0f};
+  HIPCHECK(hipMemcpy(c->coefs, hc, sizeof(hc), hipMemcpyHostToDevice));
+  for (int k = 0; k < 2; ++k) {
+    DNet& D = c->d[k];
+    Net& n = D.net;
+    for (int l = 0; l < 11; ++l) {
+      n.add(std::string("conv2d_") + kDis[l].name + "/kernel", {kDis[l].k, kDis[l].k, kDis[l].ci, kDis[l].co}, true);
+      n.add(std::string("conv2d_") + kDis[l].name + "/bias", {kDis[l].co}, true);
+    }
+    n.add("dis_9/kernel", {1, 1, 256, 1}, true);
+    n.add("dis_9/bias", {1}, true);
+    n.add("dense_1/kernel", {HW, 1}, true);
+    n.add("dense_1/bias", {1}, true);
+    n.lr = c->cfg.lrD;
+    DGCHECK(net_alloc(c, &n));
+    for (int l = 0; l < 11; ++l) {
+      const std::string nm = std::string("conv2d_") + kDis[l].name;
+      D.W[l] = n.p(nm + "/kernel"); D.b[l] = n.p(nm + "/bias");
+      D.dW[l] = n.g(nm + "/kernel"); D.db[l] = n.g(nm + "/bias");
+      D.wpf[l] = D.wpb[l] = nullptr;
+      if (c->dl[l].pf.variant >= 0) DGCHECK(dmalloc(c, &D.wpf[l], c->dl[l].pf.packedFloats));
+      if (c->dl[l].pb.variant >= 0) DGCHECK(dmalloc(c, &D.wpb[l], c->dl[l].pb.packedFloats));
+    }
+    D.w9 = n.p("dis_9/kernel"); D.b9 = n.p("dis_9/bias"); D.wd = n.p("dense_1/kernel"); D.bd = n.p("dense_1/bias");
+    D.dw9 = n.g("dis_9/kernel"); D.db9 = n.g("dis_9/bias"); D.dwd = n.g("dense_1/kernel"); D.dbd = n.g("dense_1/bias");
+  }
+  return DG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// derived state (BN affines, packed weights)
+// ---------------------------------------------------------------------------
+static int refresh_generator(depgan_ctx* c) {
+  Net& g = c->g;
+  const float eps = 1e-3f;  // keras BatchNormalization default
+  NoiseParams& np = c->np;
+  DGCHECK(dg_bn_prepare(g.p("dense_bn_noise_1_add_f0/gamma"), g.p("dense_bn_noise_1_add_f0/beta"), np.mean0,
+                        g.p("dense_bn_noise_1_add_f0/moving_variance"), eps, (float*)np.s0, (float*)np.t0,
+                        (float*)np.rstd0, 32, c->st));
+  DGCHECK(dg_bn_prepare(g.p("dense_bn_noise_1_add_f1/gamma"), g.p("dense_bn_noise_1_add_f1/beta"), np.mean1,
+                        g.p("dense_bn_noise_1_add_f1/moving_variance"), eps, (float*)np.s1, (float*)np.t1,
+                        (float*)np.rstd1, 32, c->st));
+  for (int h = 0; h < NOISE_NHEADS; ++h) {
+    const std::string bn = std::string("dense_bn_noise_2_") + kHeadSfx[h];
+    const int c0 = np.col0[h], n = np.ncol[h];
+    DGCHECK(dg_bn_prepare(g.p(bn + "/gamma"), g.p(bn + "/beta"), g.p(bn + "/moving_mean"),
+                          g.p(bn + "/moving_variance"), eps, (float*)np.sh + c0, (float*)np.th + c0,
+                          (float*)np.rstdh + c0, n, c->st));
+    HIPCHECK(hipMemcpyAsync(c->heads_mean + c0, g.p(bn + "/moving_mean"), n * sizeof(float),
+                            hipMemcpyDeviceToDevice, c->st));
+  }
+  for (size_t i = 0; i < c->gl.size(); ++i) {
+    GLayer& L = c->gl[i];
+    if (L.kind == G_CONV || L.kind == G_FILM) {
+      DGCHECK(dg_bn_prepare(L.gamma, L.beta, L.mean, L.var, eps, L.s, L.t, L.rstd, L.Cout, c->st));
+      if (L.wpf[0]) DGCHECK(dg_pack_weights(L.pf, L.Wt, L.Cin, L.Cout, 0, 0, 0, nullptr, L.wpf[0], c->st));
+      if (L.wpb[0]) DGCHECK(dg_pack_weights(L.pb, L.Wt, L.Cin, L.Cout, 0, 1, 1, L.s, L.wpb[0], c->st));
+    } else if (L.kind == G_DECONV) {
+      DGCHECK(dg_bn_prepare(L.gamma, L.beta, L.mean, L.var, eps, L.s, L.t, L.rstd, L.Cout, c->st));
+      for (int t = 0; t < 4; ++t) {
+        const float* src = L.Wt + (size_t)t * L.Cout * L.Cin;  // (kh,kw,Cout,Cin)
+        DGCHECK(dg_pack_weights(L.pf, src, L.Cin, L.Cout, 1, 0, 0, nullptr, L.wpf[t], c->st));
+        DGCHECK(dg_pack_weights(L.pb, src, L.Cin, L.Cout, 1, 1, 0, L.s, L.wpb[t], c->st));
+      }
+    }
+  }
+  return DG_OK;
+}
+
+static int refresh_critic(depgan_ctx* c, DNet& D) {
+  for (int l = 0; l < 11; ++l) {
+    const DLayer& L = c->dl[l];
+    if (D.wpf[l]) DGCHECK(dg_pack_weights(L.pf, D.W[l], L.Cin, L.Cout, 0, 0, 0, nullptr, D.wpf[l], c->st));
+    if (D.wpb[l]) DGCHECK(dg_pack_weights(L.pb, D.W[l], L.Cin, L.Cout, 0, 1, 1, nullptr, D.wpb[l], c->st));
+  }
+  return DG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// generator forward / backward
+// ---------------------------------------------------------------------------
+static int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u) {
+  {
+    ProfScope ps(c, 2, 0.0);
+    DGCHECK(dg_noise_fwd(c->np, z, c->na, n, c->st));
+  }
+  for (size_t i = 0; i < c->gl.size(); ++i) {
+    GLayer& L = c->gl[i];
+    if (L.kind == G_CONV || L.kind == G_FILM) {
+      ConvArgs a;
+      memset(&a, 0, sizeof(a));
+      zero_ep(&a.ep);
+      a.in = (i == 0) ? make_view(const_cast<float*>(x), L.H, L.W, L.Cin) : L.in;
+      a.out = L.out;
+      a.B = n; a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Cout = L.Cout;
+      a.ep.bias = L.b; a.ep.scale = L.s; a.ep.shift = L.t; a.ep.relu = 1;
+      if (L.kind == G_FILM) {
+        a.ep.film_mul = c->na.heads + L.col_mul;
+        a.ep.film_add = c->na.heads + L.col_add;
+        a.ep.film_ld = 1024;
+        a.ep.res = L.in;
+        if (store_u) a.ep.out_pre = L.u.view();
+      }
+      if (L.pf.variant >= 0) {
+        a.w = L.wpf[0];
+      } else {
+        a.w = L.Wt;
+        a.wsT = (long)L.Cin * L.Cout; a.wsI = L.Cout; a.wsO = 1; a.flip = 0;
+      }
+      DGCHECK(conv_launch(c, L.pf, a, 3));
+    } else if (L.kind == G_POOL) {
+      ProfScope ps(c, 2, 0.0);
+      DGCHECK(dg_maxpool(c->gl[L.skip_of].out, L.out, n, L.H / 2, L.W / 2, L.Cout, c->st));
+    } else if (L.kind == G_DECONV) {
+      for (int t = 0; t < 4; ++t) {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        zero_ep(&a.ep);
+        a.in = L.in;
+        a.out = strided2(L.out, t / 2, t % 2);
+        a.B = n; a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Cout = L.Cout;
+        a.ep.bias = L.b; a.ep.scale = L.s; a.ep.shift = L.t; a.ep.relu = 1;
+        a.w = L.wpf[t];
+        DGCHECK(conv_launch(c, L.pf, a, 1));
+      }
+    } else if (L.kind == G_HEAD) {
+      ProfScope ps(c, 2, 0.0);
+      DGCHECK(dg_head_fwd(L.in.p, L.Wt, L.b, c->attr.p, (long)n * L.H * L.W, L.Cin, 1, c->st));
+    }
+  }
+  return DG_OK;
+}
+
+// conv + phase-0 BN backward given dy (grad at the BN output); see _conv_bn_bwd in oracle/manual.py
+static int g_conv_bn_bwd(depgan_ctx* c, GLayer& L, size_t li, const float* x_user, TView dy, TView res, int n) {
+  TView xin = (li == 0) ? make_view(const_cast<float*>(x_user), L.H, L.W, L.Cin) : L.in;
+  {
+    ProfScope ps(c, 2, 0.0);
+    DGCHECK(dg_colsum(dy, n, L.H, L.W, L.Cout, L.s, L.db, c->Sraw, 0, c->scratch, c->st));
+    HIPCHECK(hipMemcpyAsync(L.dbeta, c->Sraw, L.Cout * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  }
+  DGCHECK(wgrad_full(c, 3, xin, dy, n, L.H, L.W, L.Cin, L.Cout, L.s, L.dW, c->raw, 0, 0));
+  {
+    ProfScope ps(c, 2, 0.0);
+    DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 9 * L.Cin, L.Cout, 0, L.Cin, L.b, L.mean, L.rstd, c->Sraw, L.dgamma,
+                             c->st));
+  }
+  if (li == 0) return DG_OK;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  zero_ep(&a.ep);
+  a.in = dy;
+  a.out = L.din;
+  a.w = L.wpb[0];
+  a.B = n; a.H = L.H; a.W = L.W; a.Cin = L.Cout; a.Cout = L.Cin;
+  a.ep.res = res;
+  a.ep.mask = L.in_mask;
+  return conv_launch(c, L.pb, a, 3);
+}
+
+static int g_backward(depgan_ctx* c, const float* x, const float* z, int n) {
+  for (int i = (int)c->gl.size() - 1; i >= 0; --i) {
+    GLayer& L = c->gl[i];
+    if (L.kind == G_HEAD) {
+      ProfScope ps(c, 2, 0.0);
+      const long P = (long)n * L.H * L.W;
+      // dW[c] = sum_p dpre[p] a[p][c] ; db = sum dpre
+      DGCHECK(dg_colsum_rowmul(L.in, n, L.H, L.W, L.Cin, c->dpre, L.dW, c->scratch, c->st));
+      DGCHECK(dg_sum(c->dpre, (size_t)P, L.db, c->scratch, c->st));
+      DGCHECK(dg_head_bwd(c->dpre, L.Wt, L.in.p, L.din.p, P, L.Cin, c->st));
+    } else if (L.kind == G_CONV) {
+      DGCHECK(g_conv_bn_bwd(c, L, (size_t)i, x, L.dout, null_view(), n));
+    } else if (L.kind == G_FILM) {
+      TView du = make_view(c->du_tmp.p, L.H, L.W, L.Cout);
+      {
+        ProfScope ps(c, 2, 0.0);
+        DGCHECK(dg_film_bwd(L.dout.p, L.u.p, c->na.heads + L.col_mul, c->na.heads + L.col_add, 1024, du.p,
+                            c->dheads + L.col_mul, c->dheads + L.col_add, n, (long)L.H * L.W, L.Cout, c->scratch,
+                            c->st));
+      }
+      DGCHECK(g_conv_bn_bwd(c, L, (size_t)i, x, du, L.dout, n));
+    } else if (L.kind == G_POOL) {
+      ProfScope ps(c, 2, 0.0);
+      DGCHECK(dg_unpool_mask(L.pool_dsrc, c->gl[L.skip_of].out, L.pool_skipgrad, L.pool_dst, n, L.H / 2, L.W / 2,
+                             L.Cout, c->st));
+    } else if (L.kind == G_DECONV) {
+      const int Ho = 2 * L.H, Wo = 2 * L.W;
+      {
+        ProfScope ps(c, 2, 0.0);
+        DGCHECK(dg_colsum(L.dout, n, Ho, Wo, L.Cout, L.s, L.db, c->Sraw, 0, c->scratch, c->st));
+        HIPCHECK(hipMemcpyAsync(L.dbeta, c->Sraw, L.Cout * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+      }
+      for (int t = 0; t < 4; ++t) {
+        const size_t o = (size_t)t * L.Cout * L.Cin;
+        DGCHECK(wgrad_full(c, 1, L.in, strided2(L.dout, t / 2, t % 2), n, L.H, L.W, L.Cin, L.Cout, L.s, L.dW + o,
+                           c->raw + o, 0, 1));
+      }
+      {
+        ProfScope ps(c, 2, 0.0);
+        DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 4 * L.Cin, L.Cout, 1, L.Cin, L.b, L.mean, L.rstd, c->Sraw, L.dgamma,
+                                 c->st));
+      }
+      for (int t = 0; t < 4; ++t) {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        zero_ep(&a.ep);
+        a.in = strided2(L.dout, t / 2, t % 2);
+        a.out = L.din;
+        a.w = L.wpb[t];
+        a.B = n; a.H = L.H; a.W = L.W; a.Cin = L.Cout; a.Cout = L.Cin;
+        a.ep.mask = L.in_mask;
+        a.ep.accumulate = (t > 0);
+        DGCHECK(conv_launch(c, L.pb, a, 1));
+      }
+    }
+  }
+  ProfScope ps(c, 2, 0.0);
+  return dg_noise_bwd(c->np, c->ng, z, c->na, c->dheads, c->scratch, n, c->st);
+}
+
+// ---------------------------------------------------------------------------
+// critic forward / backward
+// ---------------------------------------------------------------------------
+static TView d_in_view(depgan_ctx* c, int l, long s0) {  // input tensor of critic layer l (l >= 1)
+  const Tn& t = c->dl[l - 1].pool ? c->d_pool[l - 1] : c->d_act[l - 1];
+  return view_offset(t.view(), s0);
+}
+
+static int d_forward(depgan_ctx* c, DNet& D, const float* img, long s0, int N) {
+  const int H0 = c->cfg.height, W0 = c->cfg.width;
+  for (int l = 0; l < 11; ++l) {
+    const DLayer& L = c->dl[l];
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    zero_ep(&a.ep);
+    a.in = (l == 0) ? make_view(const_cast<float*>(img), H0, W0, 1) : d_in_view(c, l, s0);
+    a.out = view_offset(c->d_act[l].view(), s0);
+    a.B = N; a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Cout = L.Cout;
+    a.ep.bias = D.b[l];
+    a.ep.relu = 1;
+    if (L.pf.variant >= 0) {
+      a.w = D.wpf[l];
+    } else {
+      a.w = D.W[l];
+      a.wsT = (long)L.Cin * L.Cout; a.wsI = L.Cout; a.wsO = 1; a.flip = 0;
+    }
+    DGCHECK(conv_launch(c, L.pf, a, L.KS));
+    if (L.pool) {
+      ProfScope ps(c, 2, 0.0);
+      DGCHECK(dg_maxpool(a.out, view_offset(c->d_pool[l].view(), s0), N, L.H / 2, L.W / 2, L.Cout, c->st));
+    }
+  }
+  const DLayer& T = c->dl[10];
+  const int HW = T.H * T.W;
+  ProfScope ps(c, 2, 0.0);
+  return dg_critic_tail_fwd(c->d_act[10].p + s0 * c->d_act[10].per_sample(), D.w9, D.b9, D.wd, D.bd,
+                            c->d_t9 + s0 * HW, c->d_out + s0, N, HW, 256, c->st);
+}
+
+// backward-data chain.  coefs/per: upstream d out per sample = coefs[(n)/per].
+// img_s0/img_n: sample range (relative to s0) for which the gradient wrt the image is produced into g0_out.
+static int d_backward_chain(depgan_ctx* c, DNet& D, long s0, int N, const float* coefs, int per, long img_s0,
+                            int img_n, float* g0_out) {
+  const DLayer& T = c->dl[10];
+  const int HW = T.H * T.W;
+  {
+    ProfScope ps(c, 2, 0.0);
+    DGCHECK(dg_critic_tail_bwd(c->d_act[10].p + s0 * c->d_act[10].per_sample(), D.w9, D.wd, coefs, per,
+                               c->d_dz[10].p + s0 * c->d_dz[10].per_sample(), N, HW, 256, c->st));
+  }
+  for (int l = 10; l >= 1; --l) {
+    const DLayer& L = c->dl[l];
+    const DLayer& Pv = c->dl[l - 1];
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    zero_ep(&a.ep);
+    a.in = view_offset(c->d_dz[l].view(), s0);
+    a.w = D.wpb[l];
+    a.B = N; a.H = L.H; a.W = L.W; a.Cin = L.Cout; a.Cout = L.Cin;
+    if (Pv.pool) {
+      a.out = view_offset(c->d_dpool[l - 1].view(), s0);
+    } else {
+      a.out = view_offset(c->d_dz[l - 1].view(), s0);
+      a.ep.mask = view_offset(c->d_act[l - 1].view(), s0);
+    }
+    DGCHECK(conv_launch(c, L.pb, a, L.KS));
+    if (Pv.pool) {
+      ProfScope ps(c, 2, 0.0);
+      DGCHECK(dg_unpool_mask(a.out, view_offset(c->d_act[l - 1].view(), s0), null_view(),
+                             view_offset(c->d_dz[l - 1].view(), s0), N, Pv.H / 2, Pv.W / 2, Pv.Cout, c->st));
+    }
+  }
+  if (img_n > 0) {
+    const DLayer& L = c->dl[0];
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    zero_ep(&a.ep);
+    a.in = view_offset(c->d_dz[0].view(), s0 + img_s0);
+    a.out = make_view(g0_out, L.H, L.W, 1);
+    a.B = img_n; a.H = L.H; a.W = L.W; a.Cin = L.Cout; a.Cout = 1;
+    // transposed + flipped access of the HWIO kernel (Cin_f = 1): w(tap', k = co_f, n = 0)
+    a.w = D.W[0];
+    a.wsT = (long)L.Cin * L.Cout; a.wsI = 1; a.wsO = L.Cout; a.flip = 1;
+    ConvPlan none;
+    none.variant = -1;
+    DGCHECK(conv_launch(c, none, a, L.KS));
+  }
+  return DG_OK;
+}
+
+static int net_adam(depgan_ctx* c, Net& n) {
+  n.adam_t += 1;
+  const double b1 = c->cfg.beta1, b2 = c->cfg.beta2;
+  const double t = (double)n.adam_t;
+  const double lr_t = n.lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
+  ProfScope ps(c, 2, 0.0);
+  return dg_adam(n.P, n.G, n.M, n.V, n.nTrain, (float)lr_t, (float)b1, (float)b2, c->cfg.adam_eps, c->st);
+}
+
+// ---------------------------------------------------------------------------
+// closures
+// ---------------------------------------------------------------------------
+static int critic_grads(depgan_ctx* c, int which, const float* y2, const float* x, const float* z, const float* ep,
+                        float out[2]) {
+  DNet& D = c->d[which];
+  const int B = c->cfg.batch, H0 = c->cfg.height, W0 = c->cfg.width;
+  const long HW0 = (long)H0 * W0;
+  DGCHECK(g_forward(c, x, z, B, false));
+  {
+    ProfScope ps(c, 2, 0.0);
+    DGCHECK(dg_critic_inputs(y2, x, c->cfg.nicg, c->attr.p, ep, c->d_in, B, HW0, which, c->st));
+  }
+  DGCHECK(d_forward(c, D, c->d_in, 0, 3 * B));
+  // upstream: real -1/B, fake +1/B, mixed 1 (GT:540-547)
+  DGCHECK(d_backward_chain(c, D, 0, 3 * B, c->coefs, B, 2 * B, B, c->g0));
+  float* u0 = c->d_in + 2 * B * HW0;
+  {
+    ProfScope ps(c, 2, 0.0);
+    DGCHECK(dg_gp_u0(c->g0, u0, c->norms, c->gp, c->cfg.delta, B, HW0, c->scratch, c->st));
+  }
+  // u-forward through the masks of the mixed pass, overwriting the mixed slots
+  for (int l = 0; l < 11; ++l) {
+    const DLayer& L = c->dl[l];
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    zero_ep(&a.ep);
+    a.in = (l == 0) ? make_view(u0, H0, W0, 1) : d_in_view(c, l, 2 * B);
+    TView act = view_offset(c->d_act[l].view(), 2 * B);
+    a.out = L.pool ? c->d_ufull.view() : act;
+    if (L.pool) {  // scratch has 16 channels at full size; re-view it for this layer's shape
+      a.out = make_view(c->d_ufull.p, L.H, L.W, L.Cout);
+    }
+    a.ep.mask = act;
+    a.B = B; a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Cout = L.Cout;
+    if (L.pf.variant >= 0) {
+      a.w = D.wpf[l];
+    } else {
+      a.w = D.W[l];
+      a.wsT = (long)L.Cin * L.Cout; a.wsI = L.Cout; a.wsO = 1; a.flip = 0;
+    }
+    DGCHECK(conv_launch(c, L.pf, a, L.KS));
+    if (L.pool) {
+      ProfScope ps(c, 2, 0.0);
+      DGCHECK(dg_gather_pool(a.out, act, view_offset(c->d_pool[l].view(), 2 * B), B, L.H / 2, L.W / 2, L.Cout,
+                             c->st));
+    }
+  }
+  // weight gradients: X = [a_real, a_fake, u], D = [dz_real, dz_fake, g_z] in one launch per layer
+  for (int l = 0; l < 11; ++l) {
+    const DLayer& L = c->dl[l];
+    TView xin = (l == 0) ? make_view(c->d_in, H0, W0, 1) : d_in_view(c, l, 0);
+    DGCHECK(wgrad_full(c, L.KS, xin, c->d_dz[l].view(), 3 * B, L.H, L.W, L.Cin, L.Cout, nullptr, D.dW[l], nullptr, 0,
+                       0));
+    ProfScope ps(c, 2, 0.0);
+    DGCHECK(dg_colsum(c->d_dz[l].view(), 2 * B, L.H, L.W, L.Cout, nullptr, D.db[l], nullptr, 0, c->scratch, c->st));
+  }
+  {
+    ProfScope ps(c, 2, 0.0);
+    const DLayer& T = c->dl[10];
+    const int HW = T.H * T.W;
+    HIPCHECK(hipMemsetAsync(D.dw9, 0, 256 * sizeof(float), c->st));
+    HIPCHECK(hipMemsetAsync(D.db9, 0, sizeof(float), c->st));
+    HIPCHECK(hipMemsetAsync(D.dwd, 0, HW * sizeof(float), c->st));
+    HIPCHECK(hipMemsetAsync(D.dbd, 0, sizeof(float), c->st));
+    DGCHECK(dg_critic_tail_wgrad(c->d_act[10].p, D.w9, D.b9, D.wd, c->coefs, B, 1, D.dw9, D.db9, D.dwd, D.dbd,
+                                 c->scratch, 2 * B, HW, 256, c->st));
+    DGCHECK(dg_critic_tail_wgrad(c->d_act[10].p + (size_t)2 * B * c->d_act[10].per_sample(), D.w9, D.b9, D.wd,
+                                 c->coefs + 2, B, 0, D.dw9, D.db9, D.dwd, D.dbd, c->scratch, B, HW, 256, c->st));
+    DGCHECK(dg_mean_groups(c->d_out, c->scal, 2, B, c->st));
+  }
+  float h[3];
+  HIPCHECK(hipMemcpyAsync(h, c->scal, 2 * sizeof(float), hipMemcpyDeviceToHost, c->st));
+  HIPCHECK(hipMemcpyAsync(h + 2, c->gp, sizeof(float), hipMemcpyDeviceToHost, c->st));
+  HIPCHECK(hipStreamSynchronize(c->st));
+  out[0] = h[0];
+  out[1] = h[1];
+  c->last_sums[0] = h[0] * B;
+  c->last_sums[1] = h[1] * B;
+  c->last_sums[2] = h[2] * B;
+  c->last_sums[3] = (float)B;
+  return DG_OK;
+}
+
+static int g_eval_impl(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6], bool train) {
+  const int B = c->cfg.batch, H0 = c->cfg.height, W0 = c->cfg.width;
+  const long HW0 = (long)H0 * W0, P = (long)B * HW0;
+  DGCHECK(g_forward(c, x, z, B, train));
+  {
+    ProfScope ps(c, 2, 0.0);
+    DGCHECK(dg_add_ch0(x, c->cfg.nicg, c->attr.p, c->fake_y2, P, c->st));
+  }
+  DGCHECK(d_forward(c, c->d[0], c->fake_y2, 0, B));
+  DGCHECK(d_forward(c, c->d[1], c->attr.p, B, B));
+  {
+    ProfScope ps(c, 2, 0.0);
+    DGCHECK(dg_mean_groups(c->d_out, c->scal, 2, B, c->st));
+    DGCHECK(dg_gloss_sums(x, c->cfg.nicg, y2, c->attr.p, c->cfg.im_thresh, c->scal + 4, P, c->scratch, c->st));
+  }
+  if (train) {
+    // d loss / d attr needs dD/dimage of both critics with upstream 1 per sample (GT:592)
+    DGCHECK(d_backward_chain(c, c->d[0], 0, B, c->coefs + 2, B, 0, B, c->g0));
+    DGCHECK(d_backward_chain(c, c->d[1], B, B, c->coefs + 2, B, 0, B, c->g0 + P));
+    {
+      ProfScope ps(c, 2, 0.0);
+      DGCHECK(dg_g_dpre(x, c->cfg.nicg, y2, c->attr.p, c->g0, c->g0 + P, c->dpre, B, P, c->st));
+    }
+    DGCHECK(g_backward(c, x, z, B));
+  }
+  float h[8];
+  HIPCHECK(hipMemcpyAsync(h, c->scal, 8 * sizeof(float), hipMemcpyDeviceToHost, c->st));
+  HIPCHECK(hipStreamSynchronize(c->st));
+  const double lf = h[0], lfd = h[1], sabs = h[4], swr = h[5], swf = h[6], sin_ = h[7];
+  const double m1 = 100.0 * sabs / (double)P;                        // GT:576
+  const double dv = swr / 1000.0 - swf / 1000.0;
+  const double m3 = 100.0 * dv * dv;                                 // GT:587-589
+  const double dice = (2.0 * sin_ + 1e-7) / (swr + swf + 1e-7);      // GT:153-157
+  const double m4 = 1.0 - dice;                                      // GT:583
+  out[0] = (float)(-lf - lfd + m1 + m3 + m4);                        // GT:592
+  out[1] = (float)lf;
+  out[2] = (float)lfd;
+  out[3] = (float)m1;
+  out[4] = (float)m3;
+  out[5] = (float)m4;
+  c->last_sums[0] = (float)(lf * B);
+  c->last_sums[1] = (float)(lfd * B);
+  c->last_sums[2] = (float)sabs;
+  c->last_sums[3] = (float)swr;
+  c->last_sums[4] = (float)swf;
+  c->last_sums[5] = (float)sin_;
+  c->last_sums[6] = (float)B;
+  c->last_sums[7] = (float)P;
+  return DG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+static Net* pick_net(depgan_ctx* c, int net) {
+  if (net == DEPGAN_NET_G) return &c->g;
+  if (net == DEPGAN_NET_D_Y2) return &c->d[0].net;
+  if (net == DEPGAN_NET_D_DEM) return &c->d[1].net;
+  dg_set_error("unknown net id %d", net);
+  return nullptr;
+}
+
+extern "C" {
+
+const char* depgan_last_error(void) { return dg_get_error(); }
+
+int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
+  if (!cfg || !out) { dg_set_error("depgan_create: null argument"); return DG_ERR_ARG; }
+  if (cfg->batch < 1 || cfg->height % 16 || cfg->width % 16 || cfg->height < 16 || cfg->width < 16 || cfg->nicg < 1 ||
+      cfg->nicg > 2) {
+    dg_set_error("depgan_create: need batch >= 1, height/width multiples of 16, nicg in {1,2}");
+    return DG_ERR_ARG;
+  }
+  depgan_ctx* c = new depgan_ctx();
+  c->cfg = *cfg;
+  memset(c->last_sums, 0, sizeof(c->last_sums));
+  int rc = build_generator(c);
+  if (rc == DG_OK) rc = build_critics(c);
+  if (rc == DG_OK) {
+    // slab workspace: the largest weight-gradient call of either network
+    size_t mx = 0;
+    const int B = cfg->batch;
+    for (size_t i = 0; i < c->gl.size(); ++i) {
+      const GLayer& L = c->gl[i];
+      size_t f = 0;
+      if (L.kind == G_CONV || L.kind == G_FILM)
+        f = (L.Cin >= 8) ? dg_wgrad_part_floats(3, B, L.H, L.W, L.Cin, L.Cout)
+                         : dg_wgrad_small_part_floats(3, B, L.H, L.W, L.Cin, L.Cout);
+      else if (L.kind == G_DECONV)
+        f = dg_wgrad_part_floats(1, B, L.H, L.W, L.Cin, L.Cout);
+      if (f > mx) mx = f;
+    }
+    for (int l = 0; l < 11; ++l) {
+      const DLayer& L = c->dl[l];
+      const size_t f = (L.Cin >= 8) ? dg_wgrad_part_floats(L.KS, 3 * B, L.H, L.W, L.Cin, L.Cout)
+                                    : dg_wgrad_small_part_floats(L.KS, 3 * B, L.H, L.W, L.Cin, L.Cout);
+      if (f > mx) mx = f;
+    }
+    c->partFloats = mx;
+    rc = dmalloc(c, &c->part, mx);
+  }
+  if (rc == DG_OK) rc = dmalloc(c, &c->raw, (size_t)9 * 256 * 256);
+  if (rc == DG_OK) rc = dmalloc(c, &c->Sraw, 256);
+  if (rc == DG_OK) rc = dmalloc(c, &c->scratch, (size_t)(1 << 20) + (size_t)cfg->batch * 20000);
+  if (rc == DG_OK) rc = dmalloc(c, &c->scal, 16);
+  if (rc != DG_OK) {
+    depgan_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return DG_OK;
+}
+
+void depgan_destroy(depgan_ctx* c) {
+  if (!c) return;
+  hipDeviceSynchronize();
+  for (void* p : c->allocs) hipFree(p);
+  for (ProfRec& r : c->recs) {
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  delete c;
+}
+
+int depgan_set_stream(depgan_ctx* c, void* s) {
+  c->st = (hipStream_t)s;
+  return DG_OK;
+}
+
+int depgan_param_count(depgan_ctx* c, int net) {
+  Net* n = pick_net(c, net);
+  return n ? (int)n->params.size() : -1;
+}
+
+int depgan_param_info(depgan_ctx* c, int net, int index, char* name, int name_cap, int shape[4], int* ndim,
+                      long* offset, int* trainable) {
+  Net* n = pick_net(c, net);
+  if (!n || index < 0 || index >= (int)n->params.size()) { dg_set_error("param index out of range"); return DG_ERR_ARG; }
+  const PInfo& pi = n->params[index];
+  if (name && name_cap > 0) {
+    strncpy(name, pi.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  for (int i = 0; i < 4; ++i) shape[i] = pi.shape[i];
+  *ndim = pi.ndim;
+  *offset = (long)pi.off;
+  *trainable = pi.trainable ? 1 : 0;
+  return DG_OK;
+}
+
+long depgan_arena_floats(depgan_ctx* c, int net, int arena) {
+  Net* n = pick_net(c, net);
+  if (!n) return -1;
+  return arena == DEPGAN_ARENA_NONTRAINABLE ? (long)n->nNon : (long)n->nTrain;
+}
+
+float* depgan_arena_ptr(depgan_ctx* c, int net, int arena) {
+  Net* n = pick_net(c, net);
+  if (!n) return nullptr;
+  switch (arena) {
+    case DEPGAN_ARENA_PARAMS: return n->P;
+    case DEPGAN_ARENA_NONTRAINABLE: return n->NT;
+    case DEPGAN_ARENA_GRADS: return n->G;
+    case DEPGAN_ARENA_ADAM_M: return n->M;
+    case DEPGAN_ARENA_ADAM_V: return n->V;
+  }
+  return nullptr;
+}
+
+int depgan_weights_changed(depgan_ctx* c, int net) {
+  if (net == DEPGAN_NET_G) return refresh_generator(c);
+  if (net == DEPGAN_NET_D_Y2) return refresh_critic(c, c->d[0]);
+  if (net == DEPGAN_NET_D_DEM) return refresh_critic(c, c->d[1]);
+  dg_set_error("unknown net id %d", net);
+  return DG_ERR_ARG;
+}
+
+int depgan_g_forward(depgan_ctx* c, const float* x, const float* z, float* out, int n) {
+  if (n < 1 || n > c->cfg.batch) { dg_set_error("g_forward: n must be in [1, batch]"); return DG_ERR_ARG; }
+  DGCHECK(g_forward(c, x, z, n, false));
+  HIPCHECK(hipMemcpyAsync(out, c->attr.p, (size_t)n * c->cfg.height * c->cfg.width * sizeof(float),
+                          hipMemcpyDeviceToDevice, c->st));
+  return DG_OK;
+}
+
+int depgan_d_forward(depgan_ctx* c, int net, const float* img, float* out, int n) {
+  if (net != DEPGAN_NET_D_Y2 && net != DEPGAN_NET_D_DEM) { dg_set_error("d_forward: not a critic id"); return DG_ERR_ARG; }
+  if (n < 1 || n > c->NB3) { dg_set_error("d_forward: n must be in [1, 3*batch]"); return DG_ERR_ARG; }
+  DGCHECK(d_forward(c, c->d[net - 1], img, 0, n));
+  HIPCHECK(hipMemcpyAsync(out, c->d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  return DG_OK;
+}
+
+int depgan_critic_grads(depgan_ctx* c, int net, const float* y2, const float* x, const float* z, const float* ep,
+                        float out[2]) {
+  if (net != DEPGAN_NET_D_Y2 && net != DEPGAN_NET_D_DEM) { dg_set_error("critic_grads: not a critic id"); return DG_ERR_ARG; }
+  return critic_grads(c, net - 1, y2, x, z, ep, out);
+}
+
+int depgan_apply_adam(depgan_ctx* c, int net) {
+  Net* n = pick_net(c, net);
+  if (!n) return DG_ERR_ARG;
+  DGCHECK(net_adam(c, *n));
+  return depgan_weights_changed(c, net);
+}
+
+int depgan_critic_step(depgan_ctx* c, int net, const float* y2, const float* x, const float* z, const float* ep,
+                       float out[2]) {
+  DGCHECK(depgan_critic_grads(c, net, y2, x, z, ep, out));
+  return depgan_apply_adam(c, net);
+}
+
+int depgan_g_eval(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6]) {
+  return g_eval_impl(c, x, y2, z, out, false);
+}
+int depgan_g_grads(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6]) {
+  return g_eval_impl(c, x, y2, z, out, true);
+}
+int depgan_g_step(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6]) {
+  DGCHECK(g_eval_impl(c, x, y2, z, out, true));
+  return depgan_apply_adam(c, DEPGAN_NET_G);
+}
+
+int depgan_last_sums(depgan_ctx* c, float out[8]) {
+  memcpy(out, c->last_sums, sizeof(c->last_sums));
+  return DG_OK;
+}
+
+int depgan_profile_enable(depgan_ctx* c, int on) {
+  c->prof_on = on != 0;
+  return DG_OK;
+}
+int depgan_profile_reset(depgan_ctx* c) {
+  hipStreamSynchronize(c->st);
+  for (ProfRec& r : c->recs) {
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  c->recs.clear();
+  return DG_OK;
+}
+int depgan_profile_read(depgan_ctx* c, int klass, double* total_ms, long* launches, double* flops) {
+  HIPCHECK(hipStreamSynchronize(c->st));
+  double ms = 0, fl = 0;
+  long n = 0;
+  for (ProfRec& r : c->recs)
+    if (r.klass == klass) {
+      float t = 0;
+      HIPCHECK(hipEventElapsedTime(&t, r.a, r.b));
+      ms += t;
+      fl += r.flops;
+      ++n;
+    }
+  *total_ms = ms;
+  *launches = n;
+  *flops = fl;
+  return DG_OK;
+}
+
+// ---- single operators (unit tests) ----
+static int op_conv(const float* in, const float* w_hwio, const float* bias, float* out, int B, int H, int W, int Cin,
+                   int Cout, int KS, int relu, int path, int bwd, hipStream_t st) {
+  // bwd: compute dx = conv_bwd_data(dy=in (Cout ch), W) -> out (Cin ch)
+  const int ci = bwd ? Cout : Cin, co = bwd ? Cin : Cout;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  zero_ep(&a.ep);
+  a.in = make_view(const_cast<float*>(in), H, W, ci);
+  a.out = make_view(out, H, W, co);
+  a.B = B; a.H = H; a.W = W; a.Cin = ci; a.Cout = co;
+  a.ep.bias = bias;
+  a.ep.relu = relu;
+  ConvPlan pl = dg_plan_conv(KS, ci, co);
+  if (path == 1 && pl.variant < 0) { dg_set_error("op_conv: MFMA path not available for this shape"); return DG_ERR_UNSUPPORTED; }
+  if (path != 2 && pl.variant >= 0) {
+    float* wp = nullptr;
+    HIPCHECK(hipMalloc((void**)&wp, pl.packedFloats * sizeof(float)));
+    int rc = dg_pack_weights(pl, w_hwio, Cin, Cout, 0, bwd, bwd, nullptr, wp, st);
+    if (rc == DG_OK) {
+      a.w = wp;
+      rc = dg_conv_igemm(pl, a, st);
+    }
+    hipStreamSynchronize(st);
+    hipFree(wp);
+    return rc;
+  }
+  a.w = w_hwio;
+  if (!bwd) {
+    a.wsT = (long)Cin * Cout; a.wsI = Cout; a.wsO = 1; a.flip = 0;
+  } else {
+    a.wsT = (long)Cin * Cout; a.wsI = 1; a.wsO = Cout; a.flip = 1;
+  }
+  return dg_conv_direct(KS, a, st);
+}
+
+int depgan_op_conv2d(const float* in, const float* w_hwio, const float* bias, float* out, int B, int H, int W,
+                     int Cin, int Cout, int KS, int relu, int path, void* stream) {
+  return op_conv(in, w_hwio, bias, out, B, H, W, Cin, Cout, KS, relu, path, 0, (hipStream_t)stream);
+}
+int depgan_op_conv2d_bwd_data(const float* dy, const float* w_hwio, float* dx, int B, int H, int W, int Cin,
+                              int Cout, int KS, int path, void* stream) {
+  return op_conv(dy, w_hwio, nullptr, dx, B, H, W, Cin, Cout, KS, 0, path, 1, (hipStream_t)stream);
+}
+int depgan_op_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int KS,
+                           void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const bool big = (Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 8);
+  const size_t pf = big ? dg_wgrad_part_floats(KS, B, H, W, Cin, Cout) : dg_wgrad_small_part_floats(KS, B, H, W, Cin, Cout);
+  float* part = nullptr;
+  HIPCHECK(hipMalloc((void**)&part, pf * sizeof(float)));
+  WgradArgs a;
+  a.x = make_view(const_cast<float*>(x), H, W, Cin);
+  a.dy = make_view(const_cast<float*>(dy), H, W, Cout);
+  a.part = part;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.nTiles = a.tilesPerChunk = 0;
+  int nch = 0;
+  int rc = big ? dg_wgrad(KS, a, &nch, st) : dg_wgrad_small(KS, a, &nch, st);
+  if (rc == DG_OK) rc = dg_wgrad_reduce(part, nch, KS * KS, Cin, Cout, nullptr, dw, nullptr, 0, 0, st);
+  hipStreamSynchronize(st);
+  hipFree(part);
+  return rc;
+}
+int depgan_op_maxpool(const float* in, float* out, int B, int Ho, int Wo, int C, void* stream) {
+  return dg_maxpool(make_view(const_cast<float*>(in), 2 * Ho, 2 * Wo, C), make_view(out, Ho, Wo, C), B, Ho, Wo, C,
+                    (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,221 @@
+// Noise MLP of Gen_UNet2D (GT:358-395): Dense(1->32)+BN+ReLU, Dense(32->32)+BN+ReLU
+// on z (B,32,1), Flatten -> 1024, then 14 Dense(1024->n)+BN heads that give the
+// per-sample FiLM gamma/beta vectors.  1.08 MMAC per sample: latency-bound,
+// so these are plain kernels (no MFMA), deterministic reductions.
+#include "noise.h"
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+// one block per sample, thread t = (p, f)
+__global__ __launch_bounds__(1024) void noise_trunk_fwd_kernel(NoiseParams P, const float* __restrict__ z,
+                                                              float* __restrict__ h0, float* __restrict__ a0,
+                                                              float* __restrict__ h1, float* __restrict__ a1) {
+  __shared__ float sa0[1024];
+  const int b = blockIdx.x, t = threadIdx.x, p = t >> 5, f = t & 31;
+  const float v0 = z[b * 32 + p] * P.W0[f] + P.b0[f];
+  const float r0 = fmaxf(fmaf(v0, P.s0[f], P.t0[f]), 0.f);
+  h0[(size_t)b * 1024 + t] = v0;
+  a0[(size_t)b * 1024 + t] = r0;
+  sa0[t] = r0;
+  __syncthreads();
+  float acc = P.b1[f];
+  // same left-to-right order as a plain dot product
+  float dot = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < 32; ++k) dot = fmaf(sa0[p * 32 + k], P.W1[k * 32 + f], dot);
+  acc += dot;
+  h1[(size_t)b * 1024 + t] = acc;
+  a1[(size_t)b * 1024 + t] = fmaxf(fmaf(acc, P.s1[f], P.t1[f]), 0.f);
+}
+
+// heads: lin[b][j] = flat[b] . Wh[:, j] + bh[j] ; heads[b][j] = lin*s + t
+__global__ __launch_bounds__(256) void noise_heads_fwd_kernel(NoiseParams P, const float* __restrict__ flat,
+                                                             float* __restrict__ lin, float* __restrict__ heads) {
+  __shared__ float sf[1024];
+  const int b = blockIdx.x;
+  const int j = blockIdx.y * 256 + threadIdx.x;
+  for (int k = threadIdx.x; k < 1024; k += 256) sf[k] = flat[(size_t)b * 1024 + k];
+  __syncthreads();
+  int hd = 0;
+#pragma unroll
+  for (int i = 1; i < NOISE_NHEADS; ++i)
+    if (j >= P.col0[i]) hd = i;
+  const int n = P.ncol[hd], jl = j - P.col0[hd];
+  const float* W = P.Wh[hd];
+  float acc = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < 1024; ++k) acc = fmaf(sf[k], W[(size_t)k * n + jl], acc);
+  acc += P.bh[hd][jl];
+  lin[(size_t)b * 1024 + j] = acc;
+  heads[(size_t)b * 1024 + j] = fmaf(acc, P.sh[j], P.th[j]);
+}
+
+int dg_noise_fwd(const NoiseParams& P, const float* z, NoiseActs A, int B, hipStream_t st) {
+  hipLaunchKernelGGL(noise_trunk_fwd_kernel, dim3(B), dim3(1024), 0, st, P, z, A.h0, A.a0, A.h1, A.a1);
+  HIPCHECK(hipGetLastError());
+  hipLaunchKernelGGL(noise_heads_fwd_kernel, dim3(B, 4), dim3(256), 0, st, P, A.a1, A.lin, A.heads);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+// per head column j: BN + bias gradients, and dl[b][j] = dheads*s
+__global__ void noise_heads_bwd_cols(NoiseParams P, NoiseGrads G, const float* __restrict__ dheads,
+                                     const float* __restrict__ lin, float* __restrict__ dl, int B) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 1024) return;
+  int hd = 0;
+#pragma unroll
+  for (int i = 1; i < NOISE_NHEADS; ++i)
+    if (j >= P.col0[i]) hd = i;
+  const int jl = j - P.col0[hd];
+  const float s = P.sh[j], mu = P.meanh[j], rs = P.rstdh[j];
+  float sb = 0.f, sg = 0.f, sl = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = dheads[(size_t)b * 1024 + j];
+    sb += d;
+    sg = fmaf(d, (lin[(size_t)b * 1024 + j] - mu) * rs, sg);
+    const float l = d * s;
+    dl[(size_t)b * 1024 + j] = l;
+    sl += l;
+  }
+  G.dbeta_h[hd][jl] = sb;
+  G.dgamma_h[hd][jl] = sg;
+  G.dbh[hd][jl] = sl;
+}
+// dWh[k][jl] = sum_b flat[b][k] * dl[b][j]   ; grid (1024/256 over j, 1024 over k)
+__global__ void noise_heads_bwd_w(NoiseParams P, NoiseGrads G, const float* __restrict__ flat,
+                                  const float* __restrict__ dl, int B) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  int hd = 0;
+#pragma unroll
+  for (int i = 1; i < NOISE_NHEADS; ++i)
+    if (j >= P.col0[i]) hd = i;
+  const int n = P.ncol[hd], jl = j - P.col0[hd];
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc = fmaf(flat[(size_t)b * 1024 + k], dl[(size_t)b * 1024 + j], acc);
+  G.dWh[hd][(size_t)k * n + jl] = acc;
+}
+// dflat[b][k] = sum_j dl[b][j] * Wh[k][jl]  ; one block per (b), thread per k (4 k per thread)
+__global__ __launch_bounds__(256) void noise_heads_bwd_flat(NoiseParams P, const float* __restrict__ dl,
+                                                           float* __restrict__ dflat) {
+  __shared__ float sd[1024];
+  const int b = blockIdx.x;
+  for (int j = threadIdx.x; j < 1024; j += 256) sd[j] = dl[(size_t)b * 1024 + j];
+  __syncthreads();
+  for (int k = blockIdx.y * 256 + threadIdx.x; k < 1024; k += 256 * gridDim.y) {
+    float acc = 0.f;
+    for (int hd = 0; hd < NOISE_NHEADS; ++hd) {
+      const int n = P.ncol[hd], c0 = P.col0[hd];
+      const float* W = P.Wh[hd] + (size_t)k * n;
+      for (int jl = 0; jl < n; ++jl) acc = fmaf(sd[c0 + jl], W[jl], acc);
+    }
+    dflat[(size_t)b * 1024 + k] = acc;
+  }
+}
+
+// trunk backward, one block of 1024 threads, thread t = (p, f)
+__global__ __launch_bounds__(1024) void noise_trunk_bwd_kernel(NoiseParams P, NoiseGrads G,
+                                                              const float* __restrict__ z, NoiseActs A,
+                                                              const float* __restrict__ dflat,
+                                                              float* __restrict__ dl1, float* __restrict__ dl0,
+                                                              int B) {
+  __shared__ float red[4][1024];
+  const int t = threadIdx.x, p = t >> 5, f = t & 31;
+  // ---- layer f1: BN + bias grads, dl1 ----
+  {
+    const float s = P.s1[f], mu = P.mean1[f], rs = P.rstd1[f];
+    float sb = 0.f, sg = 0.f, sl = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const size_t o = (size_t)b * 1024 + t;
+      const float dy = (A.a1[o] > 0.f) ? dflat[o] : 0.f;
+      sb += dy;
+      sg = fmaf(dy, (A.h1[o] - mu) * rs, sg);
+      const float l = dy * s;
+      dl1[o] = l;
+      sl += l;
+    }
+    red[0][t] = sb;
+    red[1][t] = sg;
+    red[2][t] = sl;
+    __syncthreads();
+    if (t < 32) {
+      float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+      for (int q = 0; q < 32; ++q) {
+        x0 += red[0][q * 32 + t];
+        x1 += red[1][q * 32 + t];
+        x2 += red[2][q * 32 + t];
+      }
+      G.dbeta1[t] = x0;
+      G.dgamma1[t] = x1;
+      G.db1[t] = x2;
+    }
+    __syncthreads();
+  }
+  // ---- dW1[fi][fo] = sum_{b,p} a0[b,p,fi] * dl1[b,p,fo] ; thread = (fi, fo) ----
+  {
+    const int fi = t >> 5, fo = t & 31;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b)
+      for (int q = 0; q < 32; ++q)
+        acc = fmaf(A.a0[(size_t)b * 1024 + q * 32 + fi], dl1[(size_t)b * 1024 + q * 32 + fo], acc);
+    G.dW1[fi * 32 + fo] = acc;
+  }
+  // ---- layer f0 ----
+  {
+    const float s = P.s0[f], mu = P.mean0[f], rs = P.rstd0[f];
+    float sb = 0.f, sg = 0.f, sl = 0.f, sw = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const size_t o = (size_t)b * 1024 + t;
+      float da0 = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) da0 = fmaf(dl1[(size_t)b * 1024 + p * 32 + k], P.W1[f * 32 + k], da0);
+      const float dy = (A.a0[o] > 0.f) ? da0 : 0.f;
+      sb += dy;
+      sg = fmaf(dy, (A.h0[o] - mu) * rs, sg);
+      const float l = dy * s;
+      dl0[o] = l;
+      sl += l;
+      sw = fmaf(z[b * 32 + p], l, sw);
+    }
+    red[0][t] = sb;
+    red[1][t] = sg;
+    red[2][t] = sl;
+    red[3][t] = sw;
+    __syncthreads();
+    if (t < 32) {
+      float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+      for (int q = 0; q < 32; ++q) {
+        x0 += red[0][q * 32 + t];
+        x1 += red[1][q * 32 + t];
+        x2 += red[2][q * 32 + t];
+        x3 += red[3][q * 32 + t];
+      }
+      G.dbeta0[t] = x0;
+      G.dgamma0[t] = x1;
+      G.db0[t] = x2;
+      G.dW0[t] = x3;
+    }
+  }
+}
+
+int dg_noise_bwd(const NoiseParams& P, const NoiseGrads& G, const float* z, NoiseActs A, const float* dheads,
+                 float* scratch, int B, hipStream_t st) {
+  float* dl = scratch;                         // [B][1024]
+  float* dflat = scratch + (size_t)B * 1024;   // [B][1024]
+  float* dl1 = scratch + (size_t)2 * B * 1024;
+  float* dl0 = scratch + (size_t)3 * B * 1024;
+  hipLaunchKernelGGL(noise_heads_bwd_cols, dim3(4), dim3(256), 0, st, P, G, dheads, A.lin, dl, B);
+  HIPCHECK(hipGetLastError());
+  hipLaunchKernelGGL(noise_heads_bwd_w, dim3(4, 1024), dim3(256), 0, st, P, G, A.a1, dl, B);
+  HIPCHECK(hipGetLastError());
+  hipLaunchKernelGGL(noise_heads_bwd_flat, dim3(B, 4), dim3(256), 0, st, P, dl, dflat);
+  HIPCHECK(hipGetLastError());
+  hipLaunchKernelGGL(noise_trunk_bwd_kernel, dim3(1), dim3(1024), 0, st, P, G, z, A, dflat, dl1, dl0, B);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}

@@ -1,0 +1,286 @@
+// Weight-gradient contraction on the fp32 matrix cores.
+//
+//   dW[tap][ci][co] = sum_{b,y,x} X[b, y+ty-p, x+tx-p, ci] * D[b, y, x, co]
+//
+// This is what Keras' Adam.get_updates differentiates for every Conv2D kernel
+// (GT:549, 568, 594), and with X = u_{l-1}, D = M_l.g_l it is also the weight
+// gradient of the gradient penalty.
+//
+// GEMM view: M = ci (MF rows), N = co (MF cols), K = pixels.  One workgroup owns
+// one (ci-tile, co-tile, tap-group) and walks a contiguous range of TH x 16
+// pixel tiles; its 4 waves split each tile by rows (split-K inside the
+// workgroup), keep one accumulator tile per tap in registers for the whole
+// range, are summed through LDS at the end and written as ONE partial slab.
+// Slabs are reduced by a separate deterministic pass (no float atomics, so a
+// step is bit-reproducible run to run).
+// A = X^T: lane (r, h) reads channel r of pixel k_h, B: channel r of the same
+// pixel of D -> both are conflict-free 32-bit LDS reads of a [pixel][MF] image.
+#include "common.h"
+
+template <int MF>
+struct MfmaW;
+template <>
+struct MfmaW<32> {
+  typedef f32x16 acc_t;
+  static constexpr int NREG = 16;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
+};
+template <>
+struct MfmaW<16> {
+  typedef f32x4 acc_t;
+  static constexpr int NREG = 4;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int j, int h) { return 4 * h + j; }
+};
+
+template <int MF, int KS, int TPW, int TH>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+  constexpr int PAD = KS / 2;
+  constexpr int TW = 16 + KS - 1;
+  constexpr int THH = TH + KS - 1;
+  constexpr int PIXT = THH * TW;
+  constexpr int NTAPS = KS * KS;
+  constexpr int NGT = NTAPS / TPW;
+  constexpr int KM = 64 / MF;          // pixels per MFMA
+  constexpr int PW = TH * 4;           // pixels per wave per tile (TH/4 rows of 16)
+  constexpr int KSTEPS = PW / KM;
+  constexpr int V = MF / 4;            // float4 per pixel row in LDS
+  constexpr int XTOT = PIXT * V;
+  constexpr int DTOT = TH * 16 * V;
+  static_assert(NTAPS % TPW == 0 && (TPW == NTAPS || TPW == KS), "tap grouping");
+  typedef typename MfmaW<MF>::acc_t acc_t;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;               // [PIXT][MF]
+  float* ds = smem + PIXT * MF;   // [TH*16][MF]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane % MF, h = lane / MF;
+  const int nCoT = (a.Cout + MF - 1) / MF;
+  int y = blockIdx.y;
+  const int tg = y % NGT;
+  y /= NGT;
+  const int co0 = (y % nCoT) * MF;
+  const int ci0 = (y / nCoT) * MF;
+  const int chunk = blockIdx.x;
+  const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + TH - 1) / TH;
+  const int t0 = chunk * a.tilesPerChunk;
+  const int t1 = min(t0 + a.tilesPerChunk, a.nTiles);
+
+  acc_t acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int j = 0; j < MfmaW<MF>::NREG; ++j) acc[t][j] = 0.f;
+
+  for (int tile = t0; tile < t1; ++tile) {
+    int t = tile;
+    const int tx0 = (t % tilesX) * 16;
+    t /= tilesX;
+    const int ty0 = (t % tilesY) * TH;
+    const int b = t / tilesY;
+    const float* xb = a.x.p + (long)b * a.x.sB;
+    const float* db = a.dy.p + (long)b * a.dy.sB;
+    __syncthreads();  // previous tile's reads done
+    for (int q = tid; q < XTOT; q += 256) {
+      const int pix = q / V, part = q - pix * V;
+      const int ly = pix / TW, lx = pix - ly * TW;
+      const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
+      const int c = ci0 + part * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin)
+        v = *reinterpret_cast<const f32x4*>(xb + (long)iy * a.x.sY + (long)ix * a.x.sX + c);
+      *reinterpret_cast<f32x4*>(xs + pix * MF + part * 4) = v;
+    }
+    for (int q = tid; q < DTOT; q += 256) {
+      const int pix = q / V, part = q - pix * V;
+      const int ly = pix >> 4, lx = pix & 15;
+      const int iy = ty0 + ly, ix = tx0 + lx;
+      const int c = co0 + part * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy < a.H && ix < a.W && c < a.Cout)
+        v = *reinterpret_cast<const f32x4*>(db + (long)iy * a.dy.sY + (long)ix * a.dy.sX + c);
+      *reinterpret_cast<f32x4*>(ds + pix * MF + part * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      const int kl = kk * KM + h;
+      const int py = wv * (TH / 4) + (kl >> 4), px = kl & 15;
+      const float bv = ds[(py * 16 + px) * MF + r];
+      const float* xrow = xs + ((py + (TPW == NTAPS ? 0 : tg)) * TW + px) * MF + r;
+#pragma unroll
+      for (int tl = 0; tl < TPW; ++tl) {
+        const int ty = (TPW == NTAPS) ? (tl / KS) : 0;  // row offset already in xrow for row groups
+        const int tx = (TPW == NTAPS) ? (tl % KS) : tl;
+        const float av = xrow[(ty * TW + tx) * MF];
+        acc[tl] = MfmaW<MF>::run(av, bv, acc[tl]);
+      }
+    }
+  }
+
+  // ---- sum the 4 waves through LDS and write one slab per workgroup ----
+  float* red = smem;  // [4][MF*MF]
+  const size_t slab = (size_t)NTAPS * a.Cin * a.Cout;
+  float* pout = a.part + (size_t)chunk * slab;
+#pragma unroll
+  for (int tl = 0; tl < TPW; ++tl) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MfmaW<MF>::NREG; ++j) red[wv * MF * MF + MfmaW<MF>::row(j, h) * MF + r] = acc[tl][j];
+    __syncthreads();
+    const int tap = tg * TPW + tl;
+    for (int e = tid; e < MF * MF; e += 256) {
+      const float s = (red[e] + red[MF * MF + e]) + (red[2 * MF * MF + e] + red[3 * MF * MF + e]);
+      const int ci = ci0 + e / MF, co = co0 + e % MF;
+      if (ci < a.Cin && co < a.Cout) pout[((size_t)tap * a.Cin + ci) * a.Cout + co] = s;
+    }
+  }
+}
+
+struct WVar {
+  int MF, KS, TPW, TH;
+};
+
+static void pick_variant(int KS, int Cin, int Cout, WVar* v) {
+  v->KS = KS;
+  v->MF = (Cin % 32 == 0 && Cout % 32 == 0) ? 32 : 16;
+  v->TH = 16;
+  v->TPW = KS * KS;
+  if (KS == 5 && v->MF == 32) {
+    v->TPW = 5;
+    v->TH = 8;
+  }
+}
+
+static void chunking(const WVar& v, int B, int H, int W, int Cin, int Cout, int* nTiles, int* tilesPerChunk,
+                     int* nchunks, int* gridY) {
+  const int tilesX = cdiv(W, 16), tilesY = cdiv(H, v.TH);
+  *nTiles = B * tilesX * tilesY;
+  *gridY = cdiv(Cin, v.MF) * cdiv(Cout, v.MF) * (v.KS * v.KS / v.TPW);
+  int want = 1536 / *gridY;
+  if (want < 1) want = 1;
+  if (want > *nTiles) want = *nTiles;
+  *tilesPerChunk = cdiv(*nTiles, want);
+  *nchunks = cdiv(*nTiles, *tilesPerChunk);
+}
+
+size_t dg_wgrad_part_floats(int KS, int B, int H, int W, int Cin, int Cout) {
+  WVar v;
+  pick_variant(KS, Cin, Cout, &v);
+  int nTiles, tpc, nch, gy;
+  chunking(v, B, H, W, Cin, Cout, &nTiles, &tpc, &nch, &gy);
+  const size_t slab = (size_t)KS * KS * Cin * Cout;
+  return (size_t)nch * slab + (size_t)cdiv(nch, 32) * slab;  // + room for the first reduction stage
+}
+
+template <int MF, int KS, int TPW, int TH>
+static int launch_wgrad(WgradArgs a, int nchunks, int gridY, hipStream_t st) {
+  constexpr int TW = 16 + KS - 1;
+  constexpr size_t lds_tiles = (size_t)((TH + KS - 1) * TW + TH * 16) * MF * sizeof(float);
+  constexpr size_t lds_red = (size_t)4 * MF * MF * sizeof(float);
+  constexpr size_t lds = lds_tiles > lds_red ? lds_tiles : lds_red;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<MF, KS, TPW, TH>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<MF, KS, TPW, TH>), dim3(nchunks, gridY), dim3(256), lds, st, a);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_wgrad(int KS, const WgradArgs& a_in, int* nchunks_out, hipStream_t st) {
+  WgradArgs a = a_in;
+  if ((a.Cin % 4) || (a.Cout % 4) || (a.x.sX % 4) || (a.x.sY % 4) || (a.x.sB % 4) || (a.dy.sX % 4) ||
+      (a.dy.sY % 4) || (a.dy.sB % 4) || (((uintptr_t)a.x.p) & 15) || (((uintptr_t)a.dy.p) & 15)) {
+    dg_set_error("dg_wgrad: channels and strides must be multiples of 4 floats (Cin=%d Cout=%d)", a.Cin, a.Cout);
+    return DG_ERR_ARG;
+  }
+  WVar v;
+  pick_variant(KS, a.Cin, a.Cout, &v);
+  int nTiles, tpc, nch, gy;
+  chunking(v, a.B, a.H, a.W, a.Cin, a.Cout, &nTiles, &tpc, &nch, &gy);
+  a.nTiles = nTiles;
+  a.tilesPerChunk = tpc;
+  *nchunks_out = nch;
+  if (KS == 3 && v.MF == 32) return launch_wgrad<32, 3, 9, 16>(a, nch, gy, st);
+  if (KS == 3 && v.MF == 16) return launch_wgrad<16, 3, 9, 16>(a, nch, gy, st);
+  if (KS == 5 && v.MF == 32) return launch_wgrad<32, 5, 5, 8>(a, nch, gy, st);
+  if (KS == 5 && v.MF == 16) return launch_wgrad<16, 5, 25, 16>(a, nch, gy, st);
+  if (KS == 1 && v.MF == 32) return launch_wgrad<32, 1, 1, 16>(a, nch, gy, st);
+  if (KS == 1 && v.MF == 16) return launch_wgrad<16, 1, 1, 16>(a, nch, gy, st);
+  dg_set_error("dg_wgrad: unsupported kernel size %d", KS);
+  return DG_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------
+// deterministic slab reduction
+// ---------------------------------------------------------------------------
+// stage: out[g][i] = sum_{c in [g*per, min((g+1)*per, nin))} in[c][i]
+__global__ void slab_reduce_stage(const float* __restrict__ in, int nin, size_t n, float* __restrict__ out, int per) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int g = blockIdx.y;
+  const int c0 = g * per, c1 = min(c0 + per, nin);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = c0;
+  for (; c + 3 < c1; c += 4) {
+    s0 += in[(size_t)c * n + i];
+    s1 += in[(size_t)(c + 1) * n + i];
+    s2 += in[(size_t)(c + 2) * n + i];
+    s3 += in[(size_t)(c + 3) * n + i];
+  }
+  for (; c < c1; ++c) s0 += in[(size_t)c * n + i];
+  out[(size_t)g * n + i] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ void slab_reduce_final(const float* __restrict__ in, int nin, int ntaps, int Cin, int Cout,
+                                  const float* __restrict__ scale, float* __restrict__ out, float* __restrict__ raw,
+                                  int accumulate, int oi) {
+  const size_t n = (size_t)ntaps * Cin * Cout;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < nin; ++c) s += in[(size_t)c * n + i];
+  const int co = (int)(i % Cout);
+  const int ci = (int)((i / Cout) % Cin);
+  const int tap = (int)(i / ((size_t)Cout * Cin));
+  const size_t o = oi ? (((size_t)tap * Cout + co) * Cin + ci) : i;
+  if (raw) raw[o] = s;
+  if (out) {
+    float v = scale ? s * scale[co] : s;
+    if (accumulate) v += out[o];
+    out[o] = v;
+  }
+}
+
+int dg_wgrad_reduce(const float* part, int nchunks, int ntaps, int Cin, int Cout, const float* scale, float* out,
+                    float* raw, int accumulate, int oi, hipStream_t st) {
+  const size_t n = (size_t)ntaps * Cin * Cout;
+  const int bx = (int)((n + 255) / 256);
+  const float* src = part;
+  int nin = nchunks;
+  if (nchunks > 48) {
+    // first stage writes behind the slabs it reads?  No: it writes into the
+    // head of the same buffer only after every group has been read, which a
+    // single launch cannot order -- so stage 1 writes to the tail region.
+    const int per = 32;
+    const int groups = cdiv(nchunks, per);
+    float* tmp = const_cast<float*>(part) + (size_t)nchunks * n;  // caller reserves 1/32 extra (see part sizing)
+    hipLaunchKernelGGL(slab_reduce_stage, dim3(bx, groups), dim3(256), 0, st, part, nchunks, n, tmp, per);
+    HIPCHECK(hipGetLastError());
+    src = tmp;
+    nin = groups;
+  }
+  hipLaunchKernelGGL(slab_reduce_final, dim3(bx), dim3(256), 0, st, src, nin, ntaps, Cin, Cout, scale, out, raw,
+                     accumulate, oi);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}

@@ -1,0 +1,236 @@
+"""Engine: one libdepgan context (generator + two critics + optimiser state) on one GPU.
+
+PyTorch-ROCm is used for device buffers of the *inputs* and for the stream
+handle only; every FLOP runs in the hand-written HIP kernels behind the C ABI
+(include/depgan.h).  Mirrors the slice of the Keras API the reference touches
+(GT:513-598): see models.py / trainers.py for the user-facing names.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from ._lib import (ARENA_ADAM_M, ARENA_ADAM_V, ARENA_GRADS, ARENA_NONTRAINABLE, ARENA_PARAMS, D2H, H2D, NET_D_DEM,
+                   NET_D_Y2, NET_G, Config, check, load)
+
+NET_IDS = {"G": NET_G, "D_y2": NET_D_Y2, "D_dem": NET_D_DEM}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Engine:
+    def __init__(self, batch, height=256, width=256, nicg=1, first_fm=32, im_thresh=0.5, delta=10.0, lrD=1e-4,
+                 lrG=1e-4, beta1=0.0, beta2=0.9, adam_eps=1e-7, device=None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.DepganError("dep_gan_im_amd needs a ROCm GPU (MI355X): torch.cuda.is_available() is False")
+        self.lib = load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        self.cfg = Config(batch, height, width, nicg, first_fm, im_thresh, delta, lrD, lrG, beta1, beta2, adam_eps)
+        self.batch, self.height, self.width, self.nicg = batch, height, width, nicg
+        h = C.c_void_p()
+        check(self.lib.depgan_create(C.byref(self.cfg), C.byref(h)), "depgan_create")
+        self.h = h
+        self._use_current_stream()
+        self._tables = {}
+
+    # ---- plumbing ----
+    def _use_current_stream(self):
+        torch = _torch()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.depgan_set_stream(self.h, C.c_void_p(s)), "depgan_set_stream")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.depgan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _dev(self, a, shape=None):
+        """float32 contiguous CUDA tensor for a numpy array / tensor (cast like Keras' feed)."""
+        torch = _torch()
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=torch.float32).contiguous()
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.float32)).to(self.device)
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError("expected input of shape %s, got %s" % (tuple(shape), tuple(t.shape)))
+        return t
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    # ---- parameter tables ----
+    def param_table(self, net):
+        nid = NET_IDS[net]
+        if nid in self._tables:
+            return self._tables[nid]
+        n = self.lib.depgan_param_count(self.h, nid)
+        out = []
+        name = C.create_string_buffer(128)
+        shape = (C.c_int * 4)()
+        ndim, off, tr = C.c_int(), C.c_long(), C.c_int()
+        for i in range(n):
+            check(self.lib.depgan_param_info(self.h, nid, i, name, 128, shape, C.byref(ndim), C.byref(off),
+                                             C.byref(tr)), "depgan_param_info")
+            out.append((name.value.decode(), tuple(shape[:ndim.value]), off.value, bool(tr.value)))
+        self._tables[nid] = out
+        return out
+
+    def _arena_np(self, net, arena):
+        nid = NET_IDS[net]
+        n = self.lib.depgan_arena_floats(self.h, nid, arena)
+        buf = np.empty(max(n, 1), np.float32)
+        ptr = self.lib.depgan_arena_ptr(self.h, nid, arena)
+        _torch().cuda.synchronize(self.device)
+        if n:
+            _lib.memcpy(buf.ctypes.data, ptr, n * 4, D2H)
+        return buf
+
+    def _read(self, net, trainable_arena):
+        tr = self._arena_np(net, trainable_arena)
+        out = OrderedDict()
+        nt = None
+        for name, shape, off, trainable in self.param_table(net):
+            size = int(np.prod(shape))
+            if trainable:
+                out[name] = tr[off:off + size].reshape(shape).copy()
+            elif trainable_arena == ARENA_PARAMS:
+                if nt is None:
+                    nt = self._arena_np(net, ARENA_NONTRAINABLE)
+                out[name] = nt[off:off + size].reshape(shape).copy()
+        return out
+
+    def get_weights(self, net):
+        """OrderedDict name -> ndarray (Keras layouts), incl. BN moving statistics."""
+        return self._read(net, ARENA_PARAMS)
+
+    def get_grads(self, net):
+        return self._read(net, ARENA_GRADS)
+
+    def get_adam_state(self, net):
+        return self._read(net, ARENA_ADAM_M), self._read(net, ARENA_ADAM_V)
+
+    def set_weights(self, net, weights):
+        nid = NET_IDS[net]
+        tr = self._arena_np(net, ARENA_PARAMS)
+        nt = self._arena_np(net, ARENA_NONTRAINABLE)
+        for name, shape, off, trainable in self.param_table(net):
+            if name not in weights:
+                continue
+            v = np.asarray(weights[name], np.float32)
+            if tuple(v.shape) != tuple(shape):
+                raise ValueError("weight %s: expected shape %s, got %s" % (name, shape, v.shape))
+            (tr if trainable else nt)[off:off + v.size] = v.reshape(-1)
+        unknown = set(weights) - {p[0] for p in self.param_table(net)}
+        if unknown:
+            raise ValueError("unknown weight names for %s: %s" % (net, sorted(unknown)[:5]))
+        for arena, buf in ((ARENA_PARAMS, tr), (ARENA_NONTRAINABLE, nt)):
+            n = self.lib.depgan_arena_floats(self.h, nid, arena)
+            if n:
+                _lib.memcpy(self.lib.depgan_arena_ptr(self.h, nid, arena), buf.ctypes.data, n * 4, H2D)
+        self._use_current_stream()
+        check(self.lib.depgan_weights_changed(self.h, nid), "depgan_weights_changed")
+
+    def grad_arena(self, net):
+        """(device pointer, number of floats) of a network's flat gradient arena (for the RCCL all-reduce)."""
+        nid = NET_IDS[net]
+        return self.lib.depgan_arena_ptr(self.h, nid, ARENA_GRADS), self.lib.depgan_arena_floats(self.h, nid, ARENA_GRADS)
+
+    # ---- forward ----
+    def g_forward(self, x, z):
+        torch = _torch()
+        x = self._dev(x)
+        z = self._dev(z).reshape(x.shape[0], -1)
+        if x.dim() != 4 or tuple(x.shape[1:]) != (self.height, self.width, self.nicg):
+            raise ValueError("generator input must be (N,%d,%d,%d), got %s" % (self.height, self.width, self.nicg,
+                                                                                tuple(x.shape)))
+        if z.shape[1] != 32:
+            raise ValueError("noise input must be (N,32,1)")
+        n = x.shape[0]
+        out = torch.empty((n, self.height, self.width, 1), dtype=torch.float32, device=self.device)
+        self._use_current_stream()
+        for i in range(0, n, self.batch):
+            m = min(self.batch, n - i)
+            check(self.lib.depgan_g_forward(self.h, self._p(x[i:i + m]), self._p(z[i:i + m]), self._p(out[i:i + m]), m),
+                  "depgan_g_forward")
+        return out
+
+    def d_forward(self, net, img):
+        torch = _torch()
+        img = self._dev(img)
+        if img.dim() != 4 or tuple(img.shape[1:]) != (self.height, self.width, 1):
+            raise ValueError("critic input must be (N,%d,%d,1), got %s" % (self.height, self.width, tuple(img.shape)))
+        n = img.shape[0]
+        out = torch.empty((n, 1), dtype=torch.float32, device=self.device)
+        self._use_current_stream()
+        cap = 3 * self.batch
+        for i in range(0, n, cap):
+            m = min(cap, n - i)
+            check(self.lib.depgan_d_forward(self.h, NET_IDS[net], self._p(img[i:i + m]), self._p(out[i:i + m]), m),
+                  "depgan_d_forward")
+        return out
+
+    # ---- closures ----
+    def _batch_inputs(self, x, y2, z, ep=None):
+        B = self.batch
+        x = self._dev(x, (B, self.height, self.width, self.nicg))
+        y2 = self._dev(y2, (B, self.height, self.width, 1))
+        z = self._dev(z).reshape(-1)
+        if z.numel() != B * 32:
+            raise ValueError("noise must be (%d,32,1)" % B)
+        if ep is not None:
+            ep = self._dev(ep).reshape(-1)
+            if ep.numel() != B:
+                raise ValueError("ep must be (%d,1,1,1)" % B)
+        return x, y2, z, ep
+
+    def critic(self, which, y2, x, z, ep, update=True):
+        x, y2, z, ep = self._batch_inputs(x, y2, z, ep)
+        out = (C.c_float * 2)()
+        self._use_current_stream()
+        fn = self.lib.depgan_critic_step if update else self.lib.depgan_critic_grads
+        check(fn(self.h, NET_IDS[which], self._p(y2), self._p(x), self._p(z), self._p(ep), out), "critic step")
+        return [float(out[0]), float(out[1])]
+
+    def generator(self, x, y2, z, mode="eval"):
+        x, y2, z, _ = self._batch_inputs(x, y2, z)
+        out = (C.c_float * 6)()
+        self._use_current_stream()
+        fn = {"eval": self.lib.depgan_g_eval, "grads": self.lib.depgan_g_grads, "step": self.lib.depgan_g_step}[mode]
+        check(fn(self.h, self._p(x), self._p(y2), self._p(z), out), "generator " + mode)
+        return [float(v) for v in out]
+
+    def apply_adam(self, net):
+        self._use_current_stream()
+        check(self.lib.depgan_apply_adam(self.h, NET_IDS[net]), "depgan_apply_adam")
+
+    def last_sums(self):
+        out = (C.c_float * 8)()
+        check(self.lib.depgan_last_sums(self.h, out), "depgan_last_sums")
+        return [float(v) for v in out]
+
+    # ---- profiling ----
+    def profile(self, on):
+        check(self.lib.depgan_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.lib.depgan_profile_reset(self.h))
+
+    def profile_read(self, klass):
+        ms, n, fl = C.c_double(), C.c_long(), C.c_double()
+        check(self.lib.depgan_profile_read(self.h, klass, C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value

@@ -1,0 +1,99 @@
+/* libdepgan -- C ABI of the MI355X-native DEP-GAN two-critic WGAN-GP hot path.
+ *
+ * The reference (febrianrachmadi/dep-gan-im) has no FFI: its boundary is the
+ * slice of the Keras API that DEP-GAN_PROB_IM_twoCritics_training_4fold.py
+ * ("GT") touches.  Each entry point below names the reference construct it
+ * replaces.  All pointers are plain device (HIP) or host pointers, no
+ * framework types.  Every function returns 0 on success; on failure
+ * depgan_last_error() describes what went wrong.  A context is not thread safe;
+ * independent contexts (one per rank / GPU) are.
+ *
+ * Tensors are NHWC fp32, Keras weight layouts (Conv2D HWIO, Conv2DTranspose
+ * (kh,kw,Cout,Cin), Dense (in,out)).
+ */
+#ifndef DEPGAN_H
+#define DEPGAN_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct depgan_ctx depgan_ctx;
+
+typedef struct depgan_config {
+  int batch;        /* per-device batch size (batchSize, GT:42)                       */
+  int height;       /* imageSize (GT:40); must be a multiple of 16                    */
+  int width;
+  int nicg;         /* generator input channels (GT:22)                               */
+  int first_fm;     /* first_fm_G (GT:35); 32                                          */
+  float im_thresh;  /* IM_TRSH (GT:25-29)                                              */
+  float delta;      /* WGAN-GP weight (GT:37)                                          */
+  float lrD, lrG;   /* GT:44-45                                                        */
+  float beta1, beta2, adam_eps; /* Adam(beta_1=0, beta_2=0.9), K.epsilon() (GT:549)    */
+} depgan_config;
+
+enum { DEPGAN_NET_G = 0, DEPGAN_NET_D_Y2 = 1, DEPGAN_NET_D_DEM = 2 };
+enum { DEPGAN_ARENA_PARAMS = 0, DEPGAN_ARENA_NONTRAINABLE = 1, DEPGAN_ARENA_GRADS = 2,
+       DEPGAN_ARENA_ADAM_M = 3, DEPGAN_ARENA_ADAM_V = 4 };
+
+const char* depgan_last_error(void);
+
+/* Gen_UNet2D(...) + 2 x Dis_C2D_FCN1(...) + the loss graph of GT:513-598.
+ * Weights start zeroed: load them with depgan_arena_ptr + depgan_weights_changed. */
+int depgan_create(const depgan_config* cfg, depgan_ctx** out);
+void depgan_destroy(depgan_ctx* ctx);
+/* all work is enqueued on this hipStream_t (default: the null stream) */
+int depgan_set_stream(depgan_ctx* ctx, void* hip_stream);
+
+/* model.trainable_weights / get_weights / set_weights (GT:549, 892; GE:383) */
+int depgan_param_count(depgan_ctx* ctx, int net);
+int depgan_param_info(depgan_ctx* ctx, int net, int index, char* name, int name_cap, int shape[4], int* ndim,
+                      long* offset, int* trainable);
+long depgan_arena_floats(depgan_ctx* ctx, int net, int arena);
+float* depgan_arena_ptr(depgan_ctx* ctx, int net, int arena); /* device pointer */
+/* call after writing into a PARAMS / NONTRAINABLE arena from outside */
+int depgan_weights_changed(depgan_ctx* ctx, int net);
+
+/* Model.predict (GT:846-848, 859; GE:621): n <= batch samples, learning phase 0 */
+int depgan_g_forward(depgan_ctx* ctx, const float* x_dev, const float* z_dev, float* out_dev, int n);
+int depgan_d_forward(depgan_ctx* ctx, int net, const float* img_dev, float* out_dev, int n);
+
+/* netD_y2_train / netD_dem_train ([y2, x, z, ep] -> [loss_real, loss_fake]; GT:550-552, 569-571).
+ * *_grads leaves d loss / d theta_D in the GRADS arena without updating (so a
+ * data-parallel caller can all-reduce it), depgan_apply_adam applies
+ * Adam.get_updates (GT:549, 568, 594); *_step does both. */
+int depgan_critic_grads(depgan_ctx* ctx, int net, const float* y2_dev, const float* x_dev, const float* z_dev,
+                        const float* ep_dev, float out_host[2]);
+int depgan_critic_step(depgan_ctx* ctx, int net, const float* y2_dev, const float* x_dev, const float* z_dev,
+                       const float* ep_dev, float out_host[2]);
+/* netG_no_update / netG_train ([x, y2, z] -> [loss, loss_fake, loss_fake_dem, M1, M3, M4]; GT:595-598) */
+int depgan_g_eval(depgan_ctx* ctx, const float* x_dev, const float* y2_dev, const float* z_dev, float out_host[6]);
+int depgan_g_grads(depgan_ctx* ctx, const float* x_dev, const float* y2_dev, const float* z_dev, float out_host[6]);
+int depgan_g_step(depgan_ctx* ctx, const float* x_dev, const float* y2_dev, const float* z_dev, float out_host[6]);
+int depgan_apply_adam(depgan_ctx* ctx, int net);
+
+/* Un-normalised pieces of the last critic / generator evaluation, for exact
+ * data-parallel reporting: critic: [sum D(real), sum D(fake), sum (norm-1)^2, n];
+ * generator: [sum D_y2(fake), sum D_dem(attr), sum |attr-real_dem|, sum wr, sum wf, sum wr*wf, n, n*H*W]. */
+int depgan_last_sums(depgan_ctx* ctx, float out_host[8]);
+
+/* per-kernel-class device timing (HIP events on the context stream) */
+int depgan_profile_enable(depgan_ctx* ctx, int on);
+/* class 0: MFMA conv (fwd / bwd-data / u-forward), 1: MFMA wgrad, 2: everything else */
+int depgan_profile_read(depgan_ctx* ctx, int klass, double* total_ms, long* launches, double* flops);
+int depgan_profile_reset(depgan_ctx* ctx);
+
+/* ---- single operators (unit-test surface; device pointers) ---- */
+/* path: 0 auto, 1 MFMA implicit GEMM, 2 direct */
+int depgan_op_conv2d(const float* in, const float* w_hwio, const float* bias, float* out, int B, int H, int W,
+                     int Cin, int Cout, int KS, int relu, int path, void* hip_stream);
+int depgan_op_conv2d_bwd_data(const float* dy, const float* w_hwio, float* dx, int B, int H, int W, int Cin,
+                              int Cout, int KS, int path, void* hip_stream);
+int depgan_op_conv2d_wgrad(const float* x, const float* dy, float* dw_hwio, int B, int H, int W, int Cin, int Cout,
+                           int KS, void* hip_stream);
+int depgan_op_maxpool(const float* in, float* out, int B, int Ho, int Wo, int C, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
