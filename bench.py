@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 2-D slices/sec of the DEP-GAN two-critic WGAN-GP train step.
+
+One "step" = the canonical unit of SURVEY.md 8(d): one critic-Y2 update, one
+critic-DEM update and one generator update (GT:809, 824, 878) on one batch of
+synthetic 256x256x1 slices, fp32, per-GPU batch 32 (BASELINE.json configs[1]).
+Inputs are resident in HBM before the timed region.  With --gpus N > 1 the
+driver launches this file under torch.distributed.run, one rank per GPU; the
+batch is sharded (weak scaling) and each network update all-reduces its flat
+gradient arena over RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline:     MFMA implicit-GEMM convolution class (dominant kernels) --
+                algorithmic FLOPs / HIP-event time, measured live on extra steps
+                outside the timed region, against the 157.3 TFLOP/s fp32 matrix peak
+  cpu_baseline: the CPU oracle (a port: the Keras/TF reference cannot run) timed
+                on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_SLICE = 209.0          # canonical step, SURVEY 8(d)
+PEAK_F32_MFMA = 157.3            # TFLOP/s, MI355X_MICROARCH.md chip table
+
+
+def synth(seed, B, H=256, W=256):
+    """Same construction as SURVEY App. C (kept here so the product path does not import oracle/)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    mask = (((yy - 128) / 100.0) ** 2 + ((xx - 128) / 80.0) ** 2) <= 1.0
+    x0 = np.zeros((B, H, W))
+    y2 = np.zeros((B, H, W))
+    for b in range(B):
+        K = int(rng.integers(3, 9))
+        cy, cx = 128 + rng.uniform(-70, 70, K), 128 + rng.uniform(-55, 55, K)
+        amp, sig = rng.uniform(0.3, 1.0, K), rng.uniform(2.0, 8.0, K)
+        amp2, sig2 = amp * rng.uniform(0.7, 1.3, K), sig * rng.uniform(0.7, 1.3, K)
+        for k in range(K):
+            d2 = (yy - cy[k]) ** 2 + (xx - cx[k]) ** 2
+            x0[b] += amp[k] * np.exp(-d2 / (2 * sig[k] ** 2))
+            y2[b] += amp2[k] * np.exp(-d2 / (2 * sig2[k] ** 2))
+        x0[b] = np.clip(x0[b] + 0.15 * rng.uniform(size=(H, W)) ** 4, 0, 1) * mask
+        y2[b] = np.clip(y2[b] + 0.15 * rng.uniform(size=(H, W)) ** 4, 0, 1) * mask
+    z = rng.normal(size=(B, 32, 1))
+    ep = rng.uniform(size=(B, 1, 1, 1))
+    return [a.astype(np.float32) for a in (x0[..., None], y2[..., None], z, ep)]
+
+
+def cpu_baseline(sample_batch):
+    """Oracle (port) timed on the host cores: one canonical step on `sample_batch` slices."""
+    import torch
+    from oracle import depgan_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    PG, PD1, PD2 = O.init_generator(1), O.init_critic(2), O.init_critic(3)
+    x, y2, z, ep = O.synth_batch(7, sample_batch)
+    tr = O.OracleTrainers(PG, PD1, PD2)
+    t0 = time.time()
+    tr.netD_y2_train([y2, x, z, ep])
+    tr.netD_dem_train([y2, x, z, ep])
+    tr.netG_train([x, y2, z])
+    dt = time.time() - t0
+    return {"value": round(sample_batch / dt, 4), "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": "one canonical step (critic-Y2 + critic-DEM + G update) at batch %d, 256x256x1 fp32, "
+                      "torch-CPU restatement of the Keras graph (oracle/depgan_oracle.py), %.1f s" % (sample_batch, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (32 = BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import dep_gan_im_amd as dg
+    from dep_gan_im_amd.build import build
+    build()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda:%d" % local)
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        from dep_gan_im_amd.dist import DataParallel
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+        dp = DataParallel()
+
+    B = args.batch
+    netG = dg.Gen_UNet2D((256, 256, 1), (32, 1), 32, 1, seed=1)
+    netD1 = dg.Dis_C2D_FCN1((256, 256, 1), seed=2)
+    netD2 = dg.Dis_C2D_FCN1((256, 256, 1), seed=3)
+    tr = dg.build_trainers(netG, netD1, netD2, batchSize=B, delta=10.0, lrD=1e-4, lrG=1e-4, IM_TRSH=0.5, dist=dp,
+                           device=dev)
+    x, y2, z, ep = [torch.from_numpy(a).to(dev) for a in synth(1000 + rank, B)]
+
+    def step():
+        tr.netD_y2_train([y2, x, z, ep])
+        tr.netD_dem_train([y2, x, z, ep])
+        tr.netG_train([x, y2, z])
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    # ---- roofline of the dominant kernel class, HIP events on the engine's stream ----
+    eng = tr.engine
+    eng.profile(True)
+    eng.profile_reset()
+    for _ in range(2):
+        step()
+    conv_ms, conv_n, conv_fl = eng.profile_read(0)
+    wg_ms, wg_n, wg_fl = eng.profile_read(1)
+    ot_ms, ot_n, _ = eng.profile_read(2)
+    eng.profile(False)
+    eng.profile_reset()
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
+                "kernel": "igemm_conv_kernel (all shapes: fwd / bwd-data / GP u-forward)",
+                "avg_launch_us": round(conv_ms / max(conv_n, 1) * 1e3, 2), "launches_per_step": conv_n // 2,
+                "wgrad": {"achieved": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2) if wg_ms > 0 else 0.0,
+                          "ms_per_step": round(wg_ms / 2, 3)},
+                "ms_per_step": {"igemm_conv": round(conv_ms / 2, 3), "wgrad": round(wg_ms / 2, 3),
+                                "other": round(ot_ms / 2, 3)},
+                "whole_step_frac": round(GFLOP_PER_SLICE * 1e9 * B / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA, 4)}
+
+    if rank == 0:
+        line = {"metric": "2D slices/sec (G+2D+GP train step), 256x256x1 fp32", "value": round(value, 3),
+                "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "DEP-GAN-IM twoCritics canonical train step (critic-Y2 + critic-DEM + G update, "
+                                       "WGAN-GP), batch %d per GPU, 256x256x1" % B,
+                           "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world},
+                "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""GPU parity, operator level, through the C ABI: every HIP convolution form
+(MFMA implicit GEMM, direct edge kernels, MFMA / VALU weight gradient) against a
+float64 torch-CPU reference of the same op, including ragged spatial sizes,
+channel counts that exercise every kernel variant and the concat/strided views."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4   # fp32 MFMA == fmaf chain; only summation order differs from the reference
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _ref_conv(x, w, b, relu):
+    y = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2).double(), torch.from_numpy(w).permute(3, 2, 0, 1).double(),
+                 None if b is None else torch.from_numpy(b).double(), padding=w.shape[0] // 2)
+    return (torch.relu(y) if relu else y).permute(0, 2, 3, 1).numpy()
+
+
+CONV_CASES = [  # B,H,W,Cin,Cout,k,path
+    (2, 32, 32, 32, 32, 3, 1), (2, 48, 40, 32, 64, 3, 1), (1, 32, 32, 224, 96, 3, 1), (2, 21, 19, 64, 160, 3, 1),
+    (2, 32, 32, 16, 16, 5, 1), (2, 32, 32, 16, 32, 5, 1), (2, 32, 32, 32, 32, 5, 1), (2, 17, 33, 32, 16, 5, 1),
+    (2, 32, 32, 128, 128, 1, 1), (2, 32, 32, 48, 48, 3, 1), (1, 16, 16, 256, 256, 3, 1),
+    (2, 32, 32, 1, 32, 3, 2), (2, 32, 32, 2, 32, 3, 2), (2, 30, 18, 1, 16, 5, 2), (2, 32, 32, 16, 1, 5, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_and_backward_data(lib, case):
+    from dep_gan_im_amd import _lib
+    B, H, W, ci, co, k, path = case
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(ci * 1000 + co + k)
+    x = rng.standard_normal((B, H, W, ci)).astype(np.float32)
+    w = (rng.standard_normal((k, k, ci, co)) / np.sqrt(k * k * ci)).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, co)).astype(np.float32)
+    xd, wd, bd, dyd = [torch.from_numpy(a).to(dev) for a in (x, w, b, dy)]
+    out = torch.full((B, H, W, co), float("nan"), device=dev)
+    _lib.check(lib.depgan_op_conv2d(P(xd), P(wd), P(bd), P(out), B, H, W, ci, co, k, 1, path, None))
+    torch.cuda.synchronize()
+    assert rel(out.cpu().numpy(), _ref_conv(x, w, b, True)) < TOL
+    dx = torch.full((B, H, W, ci), float("nan"), device=dev)
+    _lib.check(lib.depgan_op_conv2d_bwd_data(P(dyd), P(wd), P(dx), B, H, W, ci, co, k, path, None))
+    torch.cuda.synchronize()
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).double().requires_grad_(True)
+    y = F.conv2d(xt, torch.from_numpy(w).permute(3, 2, 0, 1).double(), padding=k // 2)
+    (gx,) = torch.autograd.grad(y, xt, torch.from_numpy(dy).permute(0, 3, 1, 2).double())
+    assert rel(dx.cpu().numpy(), gx.permute(0, 2, 3, 1).numpy()) < TOL
+
+
+WGRAD_CASES = [(2, 32, 32, 32, 32, 3), (3, 48, 40, 64, 64, 3), (2, 23, 17, 96, 32, 3), (2, 16, 16, 256, 256, 3),
+               (2, 32, 32, 16, 16, 5), (2, 32, 32, 16, 32, 5), (2, 32, 24, 32, 32, 5), (2, 32, 32, 128, 128, 1),
+               (2, 32, 32, 1, 32, 3), (2, 32, 32, 2, 32, 3), (2, 32, 32, 1, 16, 5), (4, 64, 64, 32, 64, 3),
+               (2, 32, 32, 48, 80, 3)]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_weight_gradient(lib, case):
+    from dep_gan_im_amd import _lib
+    B, H, W, ci, co, k = case
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(ci * 77 + co + k)
+    x = rng.standard_normal((B, H, W, ci)).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, co)).astype(np.float32)
+    xd, dyd = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+    dw = torch.full((k, k, ci, co), float("nan"), device=dev)
+    _lib.check(lib.depgan_op_conv2d_wgrad(P(xd), P(dyd), P(dw), B, H, W, ci, co, k, None))
+    torch.cuda.synchronize()
+    wt = torch.zeros((co, ci, k, k), dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2).double(), wt, padding=k // 2)
+    (gw,) = torch.autograd.grad(y, wt, torch.from_numpy(dy).permute(0, 3, 1, 2).double())
+    assert rel(dw.cpu().numpy(), gw.permute(2, 3, 1, 0).numpy()) < TOL
+    # run-to-run bit reproducibility (no float atomics in the reduction)
+    dw2 = torch.empty_like(dw)
+    _lib.check(lib.depgan_op_conv2d_wgrad(P(xd), P(dyd), P(dw2), B, H, W, ci, co, k, None))
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2)
+
+
+def test_maxpool(lib):
+    from dep_gan_im_amd import _lib
+    dev = torch.device("cuda:0")
+    x = torch.randn(3, 20, 12, 32, device=dev)
+    out = torch.empty(3, 10, 6, 32, device=dev)
+    _lib.check(lib.depgan_op_maxpool(P(x), P(out), 3, 10, 6, 32, None))
+    torch.cuda.synchronize()
+    ref = F.max_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert torch.equal(out, ref)
