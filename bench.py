@@ -58,7 +58,11 @@ def cpu_baseline(sample_batch):
     """Oracle (port) timed on the host cores: one canonical step on `sample_batch` slices."""
     import torch
     from oracle import depgan_oracle as O
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))   # the GPU box gives one GPU's share of the host (16 cores)
     torch.set_num_threads(cores)
     PG, PD1, PD2 = O.init_generator(1), O.init_critic(2), O.init_critic(3)
     x, y2, z, ep = O.synth_batch(7, sample_batch)

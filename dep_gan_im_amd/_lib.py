@@ -15,7 +15,7 @@ EXPORTS = [
     "depgan_param_info", "depgan_arena_floats", "depgan_arena_ptr", "depgan_weights_changed", "depgan_g_forward",
     "depgan_d_forward", "depgan_critic_grads", "depgan_critic_step", "depgan_g_eval", "depgan_g_grads",
     "depgan_g_step", "depgan_apply_adam", "depgan_last_sums", "depgan_profile_enable", "depgan_profile_read",
-    "depgan_profile_reset", "depgan_op_conv2d", "depgan_op_conv2d_bwd_data", "depgan_op_conv2d_wgrad",
+    "depgan_profile_reset", "depgan_profile_dump", "depgan_op_conv2d", "depgan_op_conv2d_bwd_data", "depgan_op_conv2d_wgrad",
     "depgan_op_maxpool",
 ]
 
@@ -71,6 +71,7 @@ def load():
     lib.depgan_profile_enable.argtypes = [vp, C.c_int]
     lib.depgan_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]
     lib.depgan_profile_reset.argtypes = [vp]
+    lib.depgan_profile_dump.argtypes = [vp, C.c_char_p]
     lib.depgan_op_conv2d.argtypes = [vp, vp, vp, vp] + [C.c_int] * 8 + [vp]
     lib.depgan_op_conv2d_bwd_data.argtypes = [vp, vp, vp] + [C.c_int] * 7 + [vp]
     lib.depgan_op_conv2d_wgrad.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp]

@@ -201,6 +201,98 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradArgs a) {
   }
 }
 
+// MFMA form of the edge-layer weight gradient: M = taps*Cin (<= 32), N = Cout (16 or 32),
+// K = pixels, v_mfma_f32_16x16x4_f32.  A-lane i holds the (tap, ci) row: its LDS address is the
+// pixel offset plus a per-lane tap offset into the channel-major halo tile.
+template <int KS>
+__global__ __launch_bounds__(256) void wgrad_edge_kernel(const WgradArgs a) {
+  constexpr int PAD = KS / 2;
+  constexpr int TW = 16 + KS - 1;
+  constexpr int PIXT = TW * TW;
+  constexpr int NTAPS = KS * KS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int xsz = (a.Cin * PIXT + 3) & ~3;
+  float* xs = smem;          // [Cin][PIXT]
+  float* ds = smem + xsz;    // [256][Cout]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int M = NTAPS * a.Cin;
+  const int MT = (M + 15) >> 4, NTl = a.Cout >> 4;
+  int aoff[2];
+  bool aval[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = mt * 16 + i;
+    aval[mt] = m < M;
+    const int mm = aval[mt] ? m : 0;
+    const int tap = mm / a.Cin, ci = mm - tap * a.Cin;
+    aoff[mt] = ci * PIXT + (tap / KS) * TW + (tap % KS);
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + 15) >> 4;
+  const int t0 = blockIdx.x * a.tilesPerChunk, t1 = min(t0 + a.tilesPerChunk, a.nTiles);
+  const int C4 = a.Cout >> 2;
+  for (int tile = t0; tile < t1; ++tile) {
+    int t = tile;
+    const int tx0 = (t % tilesX) * 16;
+    t /= tilesX;
+    const int ty0 = (t % tilesY) * 16;
+    const int b = t / tilesY;
+    __syncthreads();
+    for (int q = tid; q < PIXT * a.Cin; q += 256) {
+      const int pix = q / a.Cin, c = q - pix * a.Cin;
+      const int ly = pix / TW, lx = pix - ly * TW;
+      const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
+      float v = 0.f;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = a.x.p[view_off(a.x, b, iy, ix) + c];
+      xs[c * PIXT + pix] = v;
+    }
+    for (int q = tid; q < 256 * C4; q += 256) {
+      const int pix = q / C4, c = (q - pix * C4) * 4;
+      const int iy = ty0 + (pix >> 4), ix = tx0 + (pix & 15);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy < a.H && ix < a.W) v = *reinterpret_cast<const f32x4*>(a.dy.p + view_off(a.dy, b, iy, ix) + c);
+      *reinterpret_cast<f32x4*>(ds + pix * a.Cout + c) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      const int kl = kk * 4 + kq;
+      const int py = 4 * wv + (kl >> 4), px = kl & 15;
+      const int po = py * TW + px;
+      float av[2], bv[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) av[mt] = aval[mt] ? xs[aoff[mt] + po] : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) bv[nt] = (nt < NTl) ? ds[(py * 16 + px) * a.Cout + nt * 16 + i] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          if (mt < MT && nt < NTl) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* red = smem;  // [4][32*32]
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wv * 1024 + (mt * 16 + 4 * kq + j) * 32 + nt * 16 + i] = acc[mt][nt][j];
+  __syncthreads();
+  float* pout = a.part + (size_t)blockIdx.x * M * a.Cout;
+  for (int e = tid; e < M * a.Cout; e += 256) {
+    const int m = e / a.Cout, n = e - m * a.Cout;
+    const int o = m * 32 + n;
+    pout[e] = (red[o] + red[1024 + o]) + (red[2048 + o] + red[3072 + o]);
+  }
+}
+
 static void small_chunking(int B, int H, int W, int* nTiles, int* tpc, int* nch) {
   *nTiles = B * cdiv(W, 16) * cdiv(H, 16);
   int want = 1024;
@@ -228,6 +320,22 @@ int dg_wgrad_small(int KS, const WgradArgs& a_in, int* nchunks, hipStream_t st) 
   a.tilesPerChunk = tpc;
   *nchunks = nch;
   const int TW = 16 + KS - 1;
+  const bool edge = (KS * KS * a.Cin <= 32) && (a.Cout == 16 || a.Cout == 32) && (a.dy.sX % 4 == 0) &&
+                    (a.dy.sY % 4 == 0) && (a.dy.sB % 4 == 0);
+  if (edge) {
+    size_t lds = (size_t)(((a.Cin * TW * TW + 3) & ~3) + 256 * a.Cout) * sizeof(float);
+    if (lds < 4 * 1024 * sizeof(float)) lds = 4 * 1024 * sizeof(float);
+    if (KS == 3)
+      hipLaunchKernelGGL(wgrad_edge_kernel<3>, dim3(nch), dim3(256), lds, st, a);
+    else if (KS == 5)
+      hipLaunchKernelGGL(wgrad_edge_kernel<5>, dim3(nch), dim3(256), lds, st, a);
+    else {
+      dg_set_error("dg_wgrad_small: unsupported kernel size %d", KS);
+      return DG_ERR_UNSUPPORTED;
+    }
+    HIPCHECK(hipGetLastError());
+    return DG_OK;
+  }
   const size_t lds = (size_t)(a.Cin * TW * TW + 256 * a.Cout) * sizeof(float);
   if (KS == 3)
     hipLaunchKernelGGL(wgrad_small_kernel<3>, dim3(nch), dim3(256), lds, st, a);

@@ -85,6 +85,7 @@ struct ProfRec {
   hipEvent_t a, b;
   int klass;
   double flops;
+  char label[56];
 };
 
 struct depgan_ctx {

@@ -78,11 +78,13 @@ static int net_alloc(depgan_ctx* c, Net* n) {
 struct ProfScope {
   depgan_ctx* c;
   bool live;
-  ProfScope(depgan_ctx* c_, int klass, double flops) : c(c_), live(c_->prof_on) {
+  ProfScope(depgan_ctx* c_, int klass, double flops, const char* label = "") : c(c_), live(c_->prof_on) {
     if (!live) return;
     ProfRec r;
     r.klass = klass;
     r.flops = flops;
+    strncpy(r.label, label, sizeof(r.label) - 1);
+    r.label[sizeof(r.label) - 1] = 0;
     hipEventCreate(&r.a);
     hipEventCreate(&r.b);
     hipEventRecord(r.a, c->st);
@@ -95,11 +97,13 @@ struct ProfScope {
 
 static int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
   const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cin * a.Cout * KS * KS;
+  char lb[56];
+  snprintf(lb, sizeof(lb), "conv k%d b%d %dx%d %d->%d", KS, a.B, a.H, a.W, a.Cin, a.Cout);
   if (pl.variant >= 0) {
-    ProfScope ps(c, 0, fl);
+    ProfScope ps(c, 0, fl, lb);
     return dg_conv_igemm(pl, a, c->st);
   }
-  ProfScope ps(c, 2, fl);
+  ProfScope ps(c, 2, fl, lb);
   return dg_conv_direct(KS, a, c->st);
 }
 
@@ -135,19 +139,21 @@ static int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, in
   a.nTiles = a.tilesPerChunk = 0;
   int nch = 0;
   const double fl = 2.0 * N * H * W * (double)Cin * Cout * KS * KS;
+  char lb[56];
+  snprintf(lb, sizeof(lb), "wgrad k%d b%d %dx%d %d->%d", KS, N, H, W, Cin, Cout);
   if (Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 8) {
     if (dg_wgrad_part_floats(KS, N, H, W, Cin, Cout) > c->partFloats) {
       dg_set_error("wgrad slab workspace too small");
       return DG_ERR_ARG;
     }
-    ProfScope ps(c, 1, fl);
+    ProfScope ps(c, 1, fl, lb);
     DGCHECK(dg_wgrad(KS, a, &nch, c->st));
   } else {
     if (dg_wgrad_small_part_floats(KS, N, H, W, Cin, Cout) > c->partFloats) {
       dg_set_error("wgrad slab workspace too small");
       return DG_ERR_ARG;
     }
-    ProfScope ps(c, 2, fl);
+    ProfScope ps(c, 2, fl, lb);
     DGCHECK(dg_wgrad_small(KS, a, &nch, c->st));
   }
   ProfScope ps(c, 2, 0.0);
@@ -1110,6 +1116,20 @@ int depgan_profile_read(depgan_ctx* c, int klass, double* total_ms, long* launch
   *total_ms = ms;
   *launches = n;
   *flops = fl;
+  return DG_OK;
+}
+
+int depgan_profile_dump(depgan_ctx* c, const char* path) {
+  HIPCHECK(hipStreamSynchronize(c->st));
+  FILE* f = fopen(path, "w");
+  if (!f) { dg_set_error("cannot open %s", path); return DG_ERR_ARG; }
+  fprintf(f, "class,label,ms,gflop\n");
+  for (ProfRec& r : c->recs) {
+    float t = 0;
+    hipEventElapsedTime(&t, r.a, r.b);
+    fprintf(f, "%d,%s,%.4f,%.3f\n", r.klass, r.label, t, r.flops * 1e-9);
+  }
+  fclose(f);
   return DG_OK;
 }
 

@@ -387,15 +387,19 @@ __global__ void colsum_partial(TView v, long npix, int H, int W, int C4, float* 
 }
 __global__ void colsum_final(const float* __restrict__ part, int nb, int C, const float* __restrict__ scale,
                              float* __restrict__ out, float* __restrict__ raw, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  // one 256-thread block per channel
+  __shared__ float sh4[4];
+  const int c = blockIdx.x;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(size_t)b * C + c];
-  if (raw) raw[c] = s;
-  if (out) {
-    float v = scale ? s * scale[c] : s;
-    if (accumulate) v += out[c];
-    out[c] = v;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) s += part[(size_t)b * C + c];
+  s = block_sum(s, sh4);
+  if (threadIdx.x == 0) {
+    if (raw) raw[c] = s;
+    if (out) {
+      float v = scale ? s * scale[c] : s;
+      if (accumulate) v += out[c];
+      out[c] = v;
+    }
   }
 }
 static int colsum_impl(TView v, int B, int H, int W, int C, const float* scale, float* out, float* raw, int accumulate,
@@ -409,7 +413,7 @@ static int colsum_impl(TView v, int B, int H, int W, int C, const float* scale, 
   hipLaunchKernelGGL(colsum_partial, dim3(nb), dim3(256), 256 * 4 * sizeof(float), st, v, npix, H, W, C / 4, scratch,
                      ppb, rowmul);
   HIPCHECK(hipGetLastError());
-  hipLaunchKernelGGL(colsum_final, dim3(cdiv(C, 256)), dim3(256), 0, st, scratch, nb, C, scale, out, raw, accumulate);
+  hipLaunchKernelGGL(colsum_final, dim3(C), dim3(256), 0, st, scratch, nb, C, scale, out, raw, accumulate);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
@@ -676,24 +680,26 @@ __global__ void bn_gamma_grad_kernel(const float* __restrict__ W, const float* _
                                      int oi, int Cin, const float* __restrict__ bias, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const float* __restrict__ S,
                                      float* __restrict__ dgamma) {
-  const int co = blockIdx.x * blockDim.x + threadIdx.x;
-  if (co >= Cout) return;
+  // one 256-thread block per output channel
+  __shared__ float sh4[4];
+  const int co = blockIdx.x;
   float acc = 0.f;
   if (!oi) {
-    for (int k = 0; k < K; ++k) acc = fmaf(W[(size_t)k * Cout + co], dWraw[(size_t)k * Cout + co], acc);
+    for (int k = threadIdx.x; k < K; k += blockDim.x)
+      acc = fmaf(W[(size_t)k * Cout + co], dWraw[(size_t)k * Cout + co], acc);
   } else {
-    const int taps = K / Cin;
-    for (int t = 0; t < taps; ++t)
-      for (int ci = 0; ci < Cin; ++ci) {
-        const size_t o = ((size_t)t * Cout + co) * Cin + ci;
-        acc = fmaf(W[o], dWraw[o], acc);
-      }
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+      const int t = k / Cin, ci = k - t * Cin;
+      const size_t o = ((size_t)t * Cout + co) * Cin + ci;
+      acc = fmaf(W[o], dWraw[o], acc);
+    }
   }
-  dgamma[co] = rstd[co] * (acc + (bias[co] - mean[co]) * S[co]);
+  acc = block_sum(acc, sh4);
+  if (threadIdx.x == 0) dgamma[co] = rstd[co] * (acc + (bias[co] - mean[co]) * S[co]);
 }
 int dg_bn_gamma_grad(const float* W, const float* dWraw, int K, int Cout, int oi, int Cin, const float* bias,
                      const float* mean, const float* rstd, const float* S, float* dgamma, hipStream_t st) {
-  hipLaunchKernelGGL(bn_gamma_grad_kernel, dim3(cdiv(Cout, 64)), dim3(64), 0, st, W, dWraw, K, Cout, oi, Cin, bias,
+  hipLaunchKernelGGL(bn_gamma_grad_kernel, dim3(Cout), dim3(256), 0, st, W, dWraw, K, Cout, oi, Cin, bias,
                      mean, rstd, S, dgamma);
   HIPCHECK(hipGetLastError());
   return DG_OK;

@@ -230,6 +230,9 @@ class Engine:
     def profile_reset(self):
         check(self.lib.depgan_profile_reset(self.h))
 
+    def profile_dump(self, path):
+        check(self.lib.depgan_profile_dump(self.h, path.encode()))
+
     def profile_read(self, klass):
         ms, n, fl = C.c_double(), C.c_long(), C.c_double()
         check(self.lib.depgan_profile_read(self.h, klass, C.byref(ms), C.byref(n), C.byref(fl)))

@@ -82,6 +82,8 @@ int depgan_profile_enable(depgan_ctx* ctx, int on);
 /* class 0: MFMA conv (fwd / bwd-data / u-forward), 1: MFMA wgrad, 2: everything else */
 int depgan_profile_read(depgan_ctx* ctx, int klass, double* total_ms, long* launches, double* flops);
 int depgan_profile_reset(depgan_ctx* ctx);
+/* one CSV row per recorded launch: class,label,ms,gflop */
+int depgan_profile_dump(depgan_ctx* ctx, const char* path);
 
 /* ---- single operators (unit-test surface; device pointers) ---- */
 /* path: 0 auto, 1 MFMA implicit GEMM, 2 direct */

@@ -158,6 +158,7 @@ if "perf" in sys.argv:
     for k, nm in ((0, "mfma conv"), (1, "mfma wgrad"), (2, "other")):
         ms, n, fl = eng.profile_read(k)
         print("class %-10s %8.2f ms %5d launches %8.1f TF/s" % (nm, ms, n, fl/ms/1e9 if ms else 0))
+    eng.profile_dump("gpurun_out/launches.csv")
 
 nfail = sum(1 for r in RES if not r[2])
 print("\n%d checks, %d failed" % (len(RES), nfail))
