@@ -23,13 +23,13 @@ __device__ __forceinline__ long view_off(const TView& v, int b, int y, int x) {
 
 // FiLM pre-activation; kept as one function so forward and backward evaluate
 // the sign of v with the identical instruction sequence.
-__device__ __forceinline__ float film_preact(float u, float fmul, float fadd) { return fmaf(u, fmul, fadd); }
+__device__ __forceinline__ float film_preact(float u, float fmul, float fadd) { return __fadd_rn(__fmul_rn(u, fmul), fadd); }
 
 __device__ __forceinline__ void epi_store(const ConvArgs& a, const EpiChan& c, int b, int oy, int ox, int co,
                                           float acc) {
   const Epilogue& e = a.ep;
   float v = acc + c.bias;
-  if (e.scale) v = fmaf(v, c.scale, c.shift);
+  if (e.scale) v = __fadd_rn(__fmul_rn(v, c.scale), c.shift);
   if (e.out_pre.p) e.out_pre.p[view_off(e.out_pre, b, oy, ox) + co] = v;
   if (e.film_mul) v = film_preact(v, c.fmul, c.fadd);
   if (e.relu) v = fmaxf(v, 0.f);

@@ -160,45 +160,67 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     __syncthreads();
     if (s + 1 < NS) prefetch(s + 1);
     const int tg = s % NG;
-#pragma unroll
-    for (int tl = 0; tl < TAPG; ++tl) {
+    // fragments of step q+1 are read from LDS before the MFMAs of step q issue
+    // (two register sets; all indices static after unrolling)
+    constexpr int NSTEP = TAPG * NSUB;
+    f32x4 av[2][MT], bv[2];
+    auto load_frag = [&](int q, f32x4* a_, f32x4& b_) {
+      const int tl = q / NSUB, sub = q - tl * NSUB;
       const int tap = (TAPG == NTAPS) ? tl : (tg * TAPG + tl);
       const int ty = tap / KS, tx = tap - ty * KS;
       const int tapoff = (ty * TW + tx) * CKP;
 #pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub) {
-        f32x4 av[MT];
+      for (int mt = 0; mt < MT; ++mt) a_[mt] = *reinterpret_cast<const f32x4*>(xs + apix[mt] + tapoff + sub * KB);
+      b_ = *reinterpret_cast<const f32x4*>(ws + tl * (NT * CKP) + boff + sub * KB);
+    };
+    load_frag(0, av[0], bv[0]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(xs + apix[mt] + tapoff + sub * KB);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(ws + tl * (NT * CKP) + boff + sub * KB);
+    for (int q = 0; q < NSTEP; ++q) {
+      if (q + 1 < NSTEP) load_frag(q + 1, av[(q + 1) & 1], bv[(q + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = Mfma<MF>::run(av[mt][j], bv[j], acc[mt]);
-      }
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = Mfma<MF>::run(av[q & 1][mt][j], bv[q & 1][j], acc[mt]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
   // ---- epilogue ----
+  // Per-lane base pointers once, then compile-time (dy, dx) steps with 32-bit strides:
+  // the generic per-element 64-bit view arithmetic cost as much VALU time as the MFMAs.
   const int co = n0 + r;
-  if (co < a.Cout) {
-    const EpiChan ch = epi_load_chan(a.ep, b, co, a.Cout);
+  if (co >= a.Cout) return;
+  const Epilogue& e = a.ep;
+  const EpiChan ch = epi_load_chan(e, b, co, a.Cout);
+  const int oyw = ty0 + 4 * wv, oxl = tx0 + 4 * h;
+  const bool full = (ty0 + 16 <= a.H) && (tx0 + 16 <= a.W);
+  float* pout = a.out.p + view_off(a.out, b, oyw, oxl) + co;
+  const int oSY = (int)a.out.sY, oSX = (int)a.out.sX;
+  float* ppre = e.out_pre.p ? e.out_pre.p + view_off(e.out_pre, b, oyw, oxl) + co : nullptr;
+  const int pSY = (int)e.out_pre.sY, pSX = (int)e.out_pre.sX;
+  const float* pres = e.res.p ? e.res.p + view_off(e.res, b, oyw, oxl) + co : nullptr;
+  const int rSY = (int)e.res.sY, rSX = (int)e.res.sX;
+  const float* pmsk = e.mask.p ? e.mask.p + view_off(e.mask, b, oyw, oxl) + co : nullptr;
+  const int mSY = (int)e.mask.sY, mSX = (int)e.mask.sX;
+  const bool affine = e.scale != nullptr, film = e.film_mul != nullptr, relu = e.relu != 0, accum = e.accumulate != 0;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int j = 0; j < Mfma<MF>::NREG; ++j) {
-        const int m = Mfma<MF>::row(j, h);
-        int py, px;
-        if (MF == 32) {
-          py = 4 * wv + 2 * mt + (m >> 4);
-          px = m & 15;
-        } else {
-          py = 4 * wv + mt;
-          px = m;
-        }
-        const int oy = ty0 + py, ox = tx0 + px;
-        if (oy < a.H && ox < a.W) epi_store(a, ch, b, oy, ox, co, acc[mt][j]);
-      }
+    for (int j = 0; j < Mfma<MF>::NREG; ++j) {
+      const int dy = (MF == 32) ? (2 * mt + (j >> 3)) : mt;
+      const int dx = (MF == 32) ? ((j & 3) + 8 * ((j >> 2) & 1)) : j;
+      if (!full && (oyw + dy >= a.H || oxl + dx >= a.W)) continue;
+      float v = acc[mt][j] + ch.bias;
+      if (affine) v = __fadd_rn(__fmul_rn(v, ch.scale), ch.shift);
+      if (ppre) ppre[dy * pSY + dx * pSX] = v;
+      if (film) v = film_preact(v, ch.fmul, ch.fadd);
+      if (relu) v = fmaxf(v, 0.f);
+      if (pres) v += pres[dy * rSY + dx * rSX];
+      if (pmsk) v = (pmsk[dy * mSY + dx * mSX] > 0.f) ? v : 0.f;
+      float* o = pout + (dy * oSY + dx * oSX);
+      if (accum) v += *o;
+      *o = v;
     }
   }
 }

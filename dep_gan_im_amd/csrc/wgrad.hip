@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   constexpr int KM = 64 / MF;          // pixels per MFMA
   constexpr int PW = TH * 4;           // pixels per wave per tile (TH/4 rows of 16)
   constexpr int KSTEPS = PW / KM;
+  static_assert(KSTEPS % 2 == 0, "k-steps are consumed in pairs");
   constexpr int V = MF / 4;            // float4 per pixel row in LDS
   constexpr int XTOT = PIXT * V;
   constexpr int DTOT = TH * 16 * V;
@@ -108,19 +109,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       *reinterpret_cast<f32x4*>(ds + pix * MF + part * 4) = v;
     }
     __syncthreads();
-#pragma unroll 4
-    for (int kk = 0; kk < KSTEPS; ++kk) {
+    // Fragments for k-step kk+1 are read from LDS before the MFMAs of step kk issue
+    // (two register sets, static indices), so LDS latency hides under 9 x 64 MFMA cycles.
+    float afr[2][TPW], bfr[2];
+    auto load_frag = [&](int kk, float* av, float& bv) {
       const int kl = kk * KM + h;
       const int py = wv * (TH / 4) + (kl >> 4), px = kl & 15;
-      const float bv = ds[(py * 16 + px) * MF + r];
+      bv = ds[(py * 16 + px) * MF + r];
       const float* xrow = xs + ((py + (TPW == NTAPS ? 0 : tg)) * TW + px) * MF + r;
 #pragma unroll
       for (int tl = 0; tl < TPW; ++tl) {
         const int ty = (TPW == NTAPS) ? (tl / KS) : 0;  // row offset already in xrow for row groups
         const int tx = (TPW == NTAPS) ? (tl % KS) : tl;
-        const float av = xrow[(ty * TW + tx) * MF];
-        acc[tl] = MfmaW<MF>::run(av, bv, acc[tl]);
+        av[tl] = xrow[(ty * TW + tx) * MF];
       }
+    };
+    load_frag(0, afr[0], bfr[0]);
+#pragma unroll 2
+    for (int kk = 0; kk < KSTEPS; kk += 2) {
+      load_frag(kk + 1, afr[1], bfr[1]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads of step kk+1 ahead of the MFMAs of step kk
+#pragma unroll
+      for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[0][tl], bfr[0], acc[tl]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 2 < KSTEPS) load_frag(kk + 2, afr[0], bfr[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[1][tl], bfr[1], acc[tl]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
