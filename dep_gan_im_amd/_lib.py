@@ -16,7 +16,7 @@ EXPORTS = [
     "depgan_d_forward", "depgan_critic_grads", "depgan_critic_step", "depgan_g_eval", "depgan_g_grads",
     "depgan_g_step", "depgan_apply_adam", "depgan_last_sums", "depgan_profile_enable", "depgan_profile_read",
     "depgan_profile_reset", "depgan_profile_dump", "depgan_op_conv2d", "depgan_op_conv2d_bwd_data", "depgan_op_conv2d_wgrad",
-    "depgan_op_maxpool",
+    "depgan_op_maxpool", "depgan_op_conv2d_stamps",
 ]
 
 
@@ -76,6 +76,7 @@ def load():
     lib.depgan_op_conv2d_bwd_data.argtypes = [vp, vp, vp] + [C.c_int] * 7 + [vp]
     lib.depgan_op_conv2d_wgrad.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp]
     lib.depgan_op_maxpool.argtypes = [vp, vp] + [C.c_int] * 4 + [vp]
+    lib.depgan_op_conv2d_stamps.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, vp]
     _lib = lib
     return lib
 

@@ -72,6 +72,11 @@ struct ConvArgs {
   // tapidx = flip ? ntaps-1-tap : tap
   long wsT, wsI, wsO;
   int flip;
+  int vec4;  // direct kernel: all output-side views 16-byte aligned (set by the launcher)
+  // igemm only: first-wave start stagger (shader cycles; 0 = off) and number of workgroups it applies to
+  int stagger, stagger_wgs;
+  // diagnostics: when non-null, thread 0 of every workgroup writes 8 x u64 phase stamps here
+  unsigned long long* dbg;
 };
 
 struct WgradArgs {

@@ -80,6 +80,24 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a) {
     }
   }
 
+  if constexpr (COG == 4) {
+    if (a.vec4) {
+      // one 16-byte store per pixel pass instead of four dword stores (the CU is store-issue bound)
+      const int co = co0 + g * 4;
+      if (co < a.Cout) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+          const int pix = p * PPP + p0;
+          const int oy = ty0 + (pix >> 4), ox = tx0 + (pix & 15);
+          if (oy < a.H && ox < a.W) {
+            const f32x4 v = {acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
+            epi_store4(a, b, oy, ox, co, v);
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < COG; ++k) {
     const int co = co0 + g * COG + k;
@@ -111,7 +129,13 @@ static int launch_direct(const ConvArgs& a, hipStream_t st) {
   return DG_OK;
 }
 
-int dg_conv_direct(int KS, const ConvArgs& a, hipStream_t st) {
+int dg_conv_direct(int KS, const ConvArgs& a_in, hipStream_t st) {
+  ConvArgs a = a_in;
+  auto aligned = [](const TView& v) {
+    return !v.p || (!(v.sX % 4) && !(v.sY % 4) && !(v.sB % 4) && !(((uintptr_t)v.p) & 15));
+  };
+  a.vec4 = (a.Cout % 4 == 0) && aligned(a.out) && aligned(a.ep.res) && aligned(a.ep.mask) && aligned(a.ep.out_pre) &&
+           (!a.ep.film_mul || a.ep.film_ld % 4 == 0);
   const int sel = (a.Cout == 1) ? 0 : ((a.Cout <= 16) ? 1 : 2);
   if (KS == 3) {
     if (sel == 0) return launch_direct<3, 1, 1>(a, st);

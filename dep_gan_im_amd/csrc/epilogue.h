@@ -39,3 +39,47 @@ __device__ __forceinline__ void epi_store(const ConvArgs& a, const EpiChan& c, i
   if (e.accumulate) v += *o;
   *o = v;
 }
+
+// 4 consecutive output channels at once (16-byte accesses); requires 16-byte aligned views.
+__device__ __forceinline__ void epi_store4(const ConvArgs& a, int b, int oy, int ox, int co, f32x4 v) {
+  const Epilogue& e = a.ep;
+  if (e.bias) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(e.bias + co);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += t[k];
+  }
+  if (e.scale) {
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(e.scale + co);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(e.shift + co);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = __fadd_rn(__fmul_rn(v[k], sc[k]), sh[k]);
+  }
+  if (e.out_pre.p) *reinterpret_cast<f32x4*>(e.out_pre.p + view_off(e.out_pre, b, oy, ox) + co) = v;
+  if (e.film_mul) {
+    const f32x4 fm = *reinterpret_cast<const f32x4*>(e.film_mul + (long)b * e.film_ld + co);
+    const f32x4 fa = *reinterpret_cast<const f32x4*>(e.film_add + (long)b * e.film_ld + co);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = film_preact(v[k], fm[k], fa[k]);
+  }
+  if (e.relu) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+  }
+  if (e.res.p) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(e.res.p + view_off(e.res, b, oy, ox) + co);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += r[k];
+  }
+  if (e.mask.p) {
+    const f32x4 m = *reinterpret_cast<const f32x4*>(e.mask.p + view_off(e.mask, b, oy, ox) + co);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (m[k] > 0.f) ? v[k] : 0.f;
+  }
+  f32x4* o = reinterpret_cast<f32x4*>(a.out.p + view_off(a.out, b, oy, ox) + co);
+  if (e.accumulate) {
+    const f32x4 old = *o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += old[k];
+  }
+  *o = v;
+}

@@ -17,6 +17,8 @@
 // identically for A and B, which a contraction does not care about.
 // Global loads for stage s+1 are issued into registers before the MFMAs of
 // stage s and written to LDS after them (one register set, T14-style).
+#include <stdlib.h>
+
 #include "common.h"
 #include "epilogue.h"
 
@@ -67,6 +69,23 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
   float* ws = smem + PIXT * CKP;   // [TAPG][NT][CKP]
 
   const int tid = threadIdx.x;
+  // De-phase the first wave of workgroups: identical workgroups launched together run in
+  // lock-step chip-wide, so their load / store bursts serialise with the MFMA phases.
+  if (a.stagger > 0) {
+    const unsigned id = blockIdx.x + blockIdx.y * gridDim.x;
+    if (id < (unsigned)a.stagger_wgs) {
+      const float ph = (float)id * 0.6180339887f;
+      const long wait = (long)((ph - floorf(ph)) * (float)a.stagger);
+      const long t0 = __builtin_amdgcn_s_memtime();
+      while ((long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  unsigned long long* dbg = a.dbg ? a.dbg + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 : nullptr;
+  if (dbg && tid == 0) {
+    dbg[0] = __builtin_amdgcn_s_memtime();
+    dbg[6] = __builtin_amdgcn_s_memrealtime();
+    dbg[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+  }
   const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + 15) >> 4;
   int t = blockIdx.x;
   const int tx0 = (t % tilesX) * 16;
@@ -154,10 +173,13 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     for (int j = 0; j < Mfma<MF>::NREG; ++j) acc[mt][j] = 0.f;
 
   prefetch(0);
+  if (dbg && tid == 0) dbg[1] = __builtin_amdgcn_s_memtime();
   for (int s = 0; s < NS; ++s) {
     __syncthreads();
     commit(s);
     __syncthreads();
+    if (dbg && tid == 0 && s == 0) dbg[2] = __builtin_amdgcn_s_memtime();
+    if (dbg && tid == 0 && s == 1) dbg[3] = __builtin_amdgcn_s_memtime();
     if (s + 1 < NS) prefetch(s + 1);
     const int tg = s % NG;
     // fragments of step q+1 are read from LDS before the MFMAs of step q issue
@@ -186,42 +208,91 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     }
   }
 
+  if (dbg && tid == 0) dbg[4] = __builtin_amdgcn_s_memtime();
   // ---- epilogue ----
-  // Per-lane base pointers once, then compile-time (dy, dx) steps with 32-bit strides:
-  // the generic per-element 64-bit view arithmetic cost as much VALU time as the MFMAs.
-  const int co = n0 + r;
-  if (co >= a.Cout) return;
-  const Epilogue& e = a.ep;
-  const EpiChan ch = epi_load_chan(e, b, co, a.Cout);
-  const int oyw = ty0 + 4 * wv, oxl = tx0 + 4 * h;
-  const bool full = (ty0 + 16 <= a.H) && (tx0 + 16 <= a.W);
-  float* pout = a.out.p + view_off(a.out, b, oyw, oxl) + co;
-  const int oSY = (int)a.out.sY, oSX = (int)a.out.sX;
-  float* ppre = e.out_pre.p ? e.out_pre.p + view_off(e.out_pre, b, oyw, oxl) + co : nullptr;
-  const int pSY = (int)e.out_pre.sY, pSX = (int)e.out_pre.sX;
-  const float* pres = e.res.p ? e.res.p + view_off(e.res, b, oyw, oxl) + co : nullptr;
-  const int rSY = (int)e.res.sY, rSX = (int)e.res.sX;
-  const float* pmsk = e.mask.p ? e.mask.p + view_off(e.mask, b, oyw, oxl) + co : nullptr;
-  const int mSY = (int)e.mask.sY, mSX = (int)e.mask.sX;
-  const bool affine = e.scale != nullptr, film = e.film_mul != nullptr, relu = e.relu != 0, accum = e.accumulate != 0;
+  // The CU retires only about one vector-memory wave-instruction per ~100 cycles here, so the
+  // accumulator layout (lane = channel, 16 pixels per lane => 32 dword stores per lane) made the
+  // store tail as long as the MFMA phase.  Transpose each wave's 64 x NT tile through LDS and
+  // emit 16-byte accesses: 8 lanes x 16 B cover one pixel's 32 channels (one full 128-B line).
+  __syncthreads();  // every wave is done with its fragment reads; the tile region is free
+  constexpr int CP = NT + 4;
+  float* es = smem + wv * (64 * CP);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int j = 0; j < Mfma<MF>::NREG; ++j) {
-      const int dy = (MF == 32) ? (2 * mt + (j >> 3)) : mt;
-      const int dx = (MF == 32) ? ((j & 3) + 8 * ((j >> 2) & 1)) : j;
-      if (!full && (oyw + dy >= a.H || oxl + dx >= a.W)) continue;
-      float v = acc[mt][j] + ch.bias;
-      if (affine) v = __fadd_rn(__fmul_rn(v, ch.scale), ch.shift);
-      if (ppre) ppre[dy * pSY + dx * pSX] = v;
-      if (film) v = film_preact(v, ch.fmul, ch.fadd);
-      if (relu) v = fmaxf(v, 0.f);
-      if (pres) v += pres[dy * rSY + dx * rSX];
-      if (pmsk) v = (pmsk[dy * mSY + dx * mSX] > 0.f) ? v : 0.f;
-      float* o = pout + (dy * oSY + dx * oSX);
-      if (accum) v += *o;
+      const int pl = (MF == 32) ? ((2 * mt + (j >> 3)) * 16 + ((j & 3) + 8 * ((j >> 2) & 1) + 4 * h))
+                                : (mt * 16 + 4 * h + j);
+      es[pl * CP + r] = acc[mt][j];
+    }
+  }
+  constexpr int LPP = NT / 4;     // lanes per pixel
+  constexpr int PPP = 64 / LPP;   // pixels per pass
+  constexpr int NPASS = 64 / PPP;
+  const int c4 = (lane % LPP) * 4, pl0 = lane / LPP;
+  const int co = n0 + c4;
+  if (co < a.Cout) {
+    const Epilogue& e = a.ep;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+    const f32x4 bias4 = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + co) : zero4;
+    const bool affine = e.scale != nullptr, film = e.film_mul != nullptr, relu = e.relu != 0,
+               accum = e.accumulate != 0;
+    const f32x4 sc4 = affine ? *reinterpret_cast<const f32x4*>(e.scale + co) : one4;
+    const f32x4 sh4 = affine ? *reinterpret_cast<const f32x4*>(e.shift + co) : zero4;
+    const f32x4 fm4 = film ? *reinterpret_cast<const f32x4*>(e.film_mul + (long)b * e.film_ld + co) : one4;
+    const f32x4 fa4 = film ? *reinterpret_cast<const f32x4*>(e.film_add + (long)b * e.film_ld + co) : zero4;
+    const int oyw = ty0 + 4 * wv;
+    const bool full = (ty0 + 16 <= a.H) && (tx0 + 16 <= a.W);
+    float* pout = a.out.p + view_off(a.out, b, oyw, tx0) + co;
+    const int oSY = (int)a.out.sY, oSX = (int)a.out.sX;
+    float* ppre = e.out_pre.p ? e.out_pre.p + view_off(e.out_pre, b, oyw, tx0) + co : nullptr;
+    const int pSY = (int)e.out_pre.sY, pSX = (int)e.out_pre.sX;
+    const float* pres = e.res.p ? e.res.p + view_off(e.res, b, oyw, tx0) + co : nullptr;
+    const int rSY = (int)e.res.sY, rSX = (int)e.res.sX;
+    const float* pmsk = e.mask.p ? e.mask.p + view_off(e.mask, b, oyw, tx0) + co : nullptr;
+    const int mSY = (int)e.mask.sY, mSX = (int)e.mask.sX;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int pl = p * PPP + pl0;
+      const int py = pl >> 4, px = pl & 15;
+      if (!full && (oyw + py >= a.H || tx0 + px >= a.W)) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(es + pl * CP + c4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] += bias4[k];
+        if (affine) v[k] = __fadd_rn(__fmul_rn(v[k], sc4[k]), sh4[k]);
+      }
+      if (ppre) *reinterpret_cast<f32x4*>(ppre + (py * pSY + px * pSX)) = v;
+      if (film) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = film_preact(v[k], fm4[k], fa4[k]);
+      }
+      if (relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+      }
+      if (pres) {
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(pres + (py * rSY + px * rSX));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += rr[k];
+      }
+      if (pmsk) {
+        const f32x4 mm = *reinterpret_cast<const f32x4*>(pmsk + (py * mSY + px * mSX));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (mm[k] > 0.f) ? v[k] : 0.f;
+      }
+      f32x4* o = reinterpret_cast<f32x4*>(pout + (py * oSY + px * oSX));
+      if (accum) {
+        const f32x4 old = *o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += old[k];
+      }
       *o = v;
     }
+  }
+  if (dbg && tid == 0) {
+    dbg[5] = __builtin_amdgcn_s_memtime();
+    dbg[6] = __builtin_amdgcn_s_memrealtime() - dbg[6];
   }
 }
 
@@ -267,7 +338,9 @@ ConvPlan dg_plan_conv(int KS, int Cin, int Cout) {
 template <int MF, int KS, int CK, int TAPG>
 static int launch_variant(const ConvArgs& a, hipStream_t st) {
   constexpr int TW = 16 + KS - 1;
-  constexpr size_t lds = (size_t)(TW * TW * (CK + 4) + TAPG * MF * (CK + 4)) * sizeof(float);
+  constexpr size_t lds_k = (size_t)(TW * TW * (CK + 4) + TAPG * MF * (CK + 4)) * sizeof(float);
+  constexpr size_t lds_e = (size_t)4 * 64 * (MF + 4) * sizeof(float);  // epilogue transpose
+  constexpr size_t lds = lds_k > lds_e ? lds_k : lds_e;
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_kernel<MF, KS, CK, TAPG>),
@@ -280,13 +353,35 @@ static int launch_variant(const ConvArgs& a, hipStream_t st) {
   return DG_OK;
 }
 
-int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a, hipStream_t st) {
+static float stagger_factor() {
+  static float f = -1.f;
+  if (f < 0.f) {
+    const char* e = getenv("DEPGAN_STAGGER");
+    f = e ? (float)atof(e) : 0.0f;
+  }
+  return f;
+}
+
+int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
+  ConvArgs a = a_in;
+  {
+    // one wave issues K MFMAs of 64 cycles per workgroup; ~3 workgroups share a SIMD
+    const float f = stagger_factor();
+    const long K = (long)pl.KS * pl.KS * pl.nCC * pl.CK;
+    const long nwg = (long)cdiv(a.W, 16) * cdiv(a.H, 16) * a.B * cdiv(a.Cout, pl.MF);
+    a.stagger = (f > 0.f && nwg > 1536) ? (int)(f * 192.f * (float)K * (pl.MF == 16 ? 0.5f : 1.f)) : 0;
+    a.stagger_wgs = 768;
+  }
   if (pl.variant < 0) {
     dg_set_error("dg_conv_igemm: no MFMA variant for KS=%d Cin=%d Cout=%d", pl.KS, pl.Cin, pl.Cout);
     return DG_ERR_UNSUPPORTED;
   }
-  if ((a.in.sX % 4) || (a.in.sY % 4) || (a.in.sB % 4) || (((uintptr_t)a.in.p) & 15)) {
-    dg_set_error("dg_conv_igemm: input view must be 16-byte aligned (strides %% 4 floats)");
+  auto misaligned = [](const TView& v) {
+    return v.p && ((v.sX % 4) || (v.sY % 4) || (v.sB % 4) || (((uintptr_t)v.p) & 15));
+  };
+  if (misaligned(a.in) || misaligned(a.out) || misaligned(a.ep.res) || misaligned(a.ep.mask) ||
+      misaligned(a.ep.out_pre) || (a.Cout % 4) || (a.ep.film_mul && (a.ep.film_ld % 4))) {
+    dg_set_error("dg_conv_igemm: views must be 16-byte aligned (pointers, strides and Cout multiples of 4 floats)");
     return DG_ERR_ARG;
   }
   switch (pl.variant) {

@@ -1169,6 +1169,32 @@ static int op_conv(const float* in, const float* w_hwio, const float* bias, floa
   return dg_conv_direct(KS, a, st);
 }
 
+// diagnostics: run the MFMA conv with per-workgroup phase stamps (8 x u64 per workgroup) into `stamps`
+int depgan_op_conv2d_stamps(const float* in, const float* w_hwio, float* out, int B, int H, int W, int Cin, int Cout,
+                            int KS, unsigned long long* stamps, int reps, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  zero_ep(&a.ep);
+  a.in = make_view(const_cast<float*>(in), H, W, Cin);
+  a.out = make_view(out, H, W, Cout);
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.ep.relu = 1;
+  ConvPlan pl = dg_plan_conv(KS, Cin, Cout);
+  if (pl.variant < 0) { dg_set_error("no MFMA variant"); return DG_ERR_UNSUPPORTED; }
+  float* wp = nullptr;
+  HIPCHECK(hipMalloc((void**)&wp, pl.packedFloats * sizeof(float)));
+  int rc = dg_pack_weights(pl, w_hwio, Cin, Cout, 0, 0, 0, nullptr, wp, st);
+  a.w = wp;
+  for (int i = 0; i < reps && rc == DG_OK; ++i) {
+    a.dbg = (i == reps - 1) ? stamps : nullptr;
+    rc = dg_conv_igemm(pl, a, st);
+  }
+  hipStreamSynchronize(st);
+  hipFree(wp);
+  return rc;
+}
+
 int depgan_op_conv2d(const float* in, const float* w_hwio, const float* bias, float* out, int B, int H, int W,
                      int Cin, int Cout, int KS, int relu, int path, void* stream) {
   return op_conv(in, w_hwio, bias, out, B, H, W, Cin, Cout, KS, relu, path, 0, (hipStream_t)stream);
