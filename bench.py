@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (32 = BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2)
+    ap.add_argument("--cpu-sample", type=int, default=32)
     args = ap.parse_args()
 
     import torch

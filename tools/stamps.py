@@ -32,5 +32,14 @@ def run(B,H,W,ci,co,k):
     print("   alive at mid-kernel: %d WGs (%.2f per CU if 256 CUs)" % (alive.sum(), alive.sum()/256.0))
     starts = np.sort(s[:,0]-t0)
     print("   start times: first-wave (768th WG) at %d cycles; median start %d" % (starts[min(767,len(starts)-1)], np.median(starts)))
-for args in [(32,256,256,32,32,3),(32,128,128,64,64,3),(96,16,16,256,256,3),(32,64,64,96,96,3)]:
-    run(*args)
+import time
+def timeit(B,H,W,ci,co,k,n=20):
+    x = torch.randn(B,H,W,ci, device=dev); w = torch.randn(k,k,ci,co, device=dev)*0.05; out = torch.empty(B,H,W,co, device=dev)
+    lib.depgan_op_conv2d_stamps(P(x),P(w),P(out),B,H,W,ci,co,k,None,3,None); torch.cuda.synchronize()
+    t=time.time(); lib.depgan_op_conv2d_stamps(P(x),P(w),P(out),B,H,W,ci,co,k,None,n,None); torch.cuda.synchronize(); dt=(time.time()-t)/n
+    print("   time %.1f us -> %.1f TF/s" % (dt*1e6, 2.0*B*H*W*ci*co*k*k/dt/1e12))
+cases = [(32,256,256,32,32,3),(32,128,128,64,64,3),(32,64,64,96,96,3),(32,256,256,96,32,3)]
+if os.environ.get('ONEWG'): cases = [(1,256,256,32,32,3)]
+for args in cases:
+    if os.environ.get("STAMPS","1") == "1": run(*args)
+    timeit(*args)
