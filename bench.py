@@ -98,7 +98,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda:%d" % local)
     dp = None
-    if world > 1:
+    if world > 1 or os.environ.get("DEPGAN_FORCE_DIST"):   # the env switch rehearses the RCCL path on one GPU
         import torch.distributed as dist
         from dep_gan_im_amd.dist import DataParallel
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -119,7 +119,7 @@ def main():
         tr.netG_train([x, y2, z])
 
     def barrier():
-        if world > 1:
+        if dp is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -131,7 +131,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -172,7 +172,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp is not None:
         torch.distributed.destroy_process_group()
 
 

@@ -197,3 +197,39 @@ def test_data_parallel_property_on_one_gpu(lib):
     # the GP term is a mean over samples of a per-sample quantity -> also linear in the shards
     for k in g_big:
         assert rel(acc[k] / 2, g_big[k]) < 2e-3, k
+
+
+def test_rccl_path_world1_matches_single_process(lib):
+    """The data-parallel closures (grad arena aliased as a torch tensor, RCCL all-reduce, global-sum
+    scalars) on a 1-rank 'nccl' group must reproduce the plain closures exactly."""
+    import socket
+    import torch.distributed as dist
+    import dep_gan_im_amd as dg
+    from dep_gan_im_amd.dist import DataParallel
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        img, B = 64, 2
+        PG, PD1, PD2, x, y2, z, ep = _setup(img, B, 61, noisy=True)
+        outs, weights = [], []
+        for use_dist in (False, True):
+            nets = [dg.Gen_UNet2D((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1))]
+            for n, P in zip(nets, (PG, PD1, PD2)):
+                n.set_weights({k: v.copy() for k, v in P.items()})
+            tr = dg.build_trainers(*nets, batchSize=B, dist=DataParallel() if use_dist else None)
+            o = tr.netD_y2_train([y2, x, z, ep]) + tr.netD_dem_train([y2, x, z, ep]) + tr.netG_no_update([x, y2, z]) \
+                + tr.netG_train([x, y2, z])
+            outs.append(o)
+            weights.append([n.get_weights_dict() for n in nets])
+        np.testing.assert_allclose(outs[0], outs[1], rtol=2e-6, atol=1e-7)
+        for wa, wb in zip(weights[0], weights[1]):
+            for k in wa:
+                np.testing.assert_array_equal(wa[k], wb[k])
+    finally:
+        dist.destroy_process_group()
