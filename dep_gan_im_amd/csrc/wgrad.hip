@@ -39,7 +39,7 @@ struct MfmaW<16> {
 };
 
 template <int MF, int KS, int TPW, int TH>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   constexpr int PAD = KS / 2;
   constexpr int TW = 16 + KS - 1;
   constexpr int THH = TH + KS - 1;
@@ -79,53 +79,88 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < MfmaW<MF>::NREG; ++j) acc[t][j] = 0.f;
 
+  // fp32 MFMA shares the vector ALUs with every VALU instruction on the SIMD, so the tile loop is
+  // written to issue almost none: per-thread staging offsets are computed once per workgroup,
+  // interior tiles skip all bounds logic, and the fully unrolled k-loop reads its fragments with
+  // compile-time LDS offsets from two per-lane base addresses.
+  constexpr int NXP = (XTOT + 255) / 256, NDP = (DTOT + 255) / 256;
+  static_assert((V & (V - 1)) == 0, "channel parts per pixel must be a power of two");
+  int xofs[NXP];              // element offset of piece i relative to the tile origin (may be negative)
+#pragma unroll
+  for (int i = 0; i < NXP; ++i) {
+    const int q = tid + i * 256;
+    const int pix = q / V, part = q & (V - 1);
+    const int ly = pix / TW, lx = pix - ly * TW;
+    xofs[i] = (ly - PAD) * (int)a.x.sY + (lx - PAD) * (int)a.x.sX + part * 4;
+  }
+  const int dpart = (tid & (V - 1)) * 4;
+  const bool cxok = (ci0 + dpart) < a.Cin, cdok = (co0 + dpart) < a.Cout;
+  // per-lane fragment bases (k-step and tap offsets are compile-time immediates)
+  const float* bbase = ds + ((wv * (TH / 4)) * 16 + h) * MF + r;
+  const float* xbase = xs + ((wv * (TH / 4) + (TPW == NTAPS ? 0 : tg)) * TW + h) * MF + r;
+
   for (int tile = t0; tile < t1; ++tile) {
     int t = tile;
     const int tx0 = (t % tilesX) * 16;
     t /= tilesX;
     const int ty0 = (t % tilesY) * TH;
     const int b = t / tilesY;
-    const float* xb = a.x.p + (long)b * a.x.sB;
-    const float* db = a.dy.p + (long)b * a.dy.sB;
+    const float* xb = a.x.p + ((long)b * a.x.sB + (long)ty0 * a.x.sY + (long)tx0 * a.x.sX + ci0);
+    const float* db = a.dy.p + ((long)b * a.dy.sB + (long)ty0 * a.dy.sY + (long)tx0 * a.dy.sX + co0);
+    const bool interior = ty0 >= PAD && ty0 + TH + PAD <= a.H && tx0 >= PAD && tx0 + 16 + PAD <= a.W;
     __syncthreads();  // previous tile's reads done
-    for (int q = tid; q < XTOT; q += 256) {
-      const int pix = q / V, part = q - pix * V;
-      const int ly = pix / TW, lx = pix - ly * TW;
-      const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
-      const int c = ci0 + part * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin)
-        v = *reinterpret_cast<const f32x4*>(xb + (long)iy * a.x.sY + (long)ix * a.x.sX + c);
-      *reinterpret_cast<f32x4*>(xs + pix * MF + part * 4) = v;
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < NXP; ++i) {
+        if ((i + 1) * 256 <= XTOT || tid + i * 256 < XTOT) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (cxok) v = *reinterpret_cast<const f32x4*>(xb + xofs[i]);
+          *reinterpret_cast<f32x4*>(xs + (tid + i * 256) * 4) = v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NXP; ++i) {
+        if ((i + 1) * 256 <= XTOT || tid + i * 256 < XTOT) {
+          const int pix = (tid + i * 256) / V;          // border tiles only: recompute the halo coordinates
+          const int ly = pix / TW, lx = pix - ly * TW;
+          const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (cxok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *reinterpret_cast<const f32x4*>(xb + xofs[i]);
+          *reinterpret_cast<f32x4*>(xs + (tid + i * 256) * 4) = v;
+        }
+      }
     }
-    for (int q = tid; q < DTOT; q += 256) {
-      const int pix = q / V, part = q - pix * V;
-      const int ly = pix >> 4, lx = pix & 15;
-      const int iy = ty0 + ly, ix = tx0 + lx;
-      const int c = co0 + part * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy < a.H && ix < a.W && c < a.Cout)
-        v = *reinterpret_cast<const f32x4*>(db + (long)iy * a.dy.sY + (long)ix * a.dy.sX + c);
-      *reinterpret_cast<f32x4*>(ds + pix * MF + part * 4) = v;
+    __builtin_amdgcn_sched_barrier(0);  // bound the staging registers: X pieces are in LDS before D loads issue
+#pragma unroll
+    for (int i = 0; i < NDP; ++i) {
+      if ((i + 1) * 256 <= DTOT || tid + i * 256 < DTOT) {
+        const int q = tid + i * 256;
+        const int pix = q / V;              // V is a power of two: shifts
+        const int ly = pix >> 4, lx = pix & 15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (cdok && (interior || (ty0 + ly < a.H && tx0 + lx < a.W)))
+          v = *reinterpret_cast<const f32x4*>(db + (ly * (int)a.dy.sY + lx * (int)a.dy.sX + dpart));
+        *reinterpret_cast<f32x4*>(ds + q * 4) = v;
+      }
     }
     __syncthreads();
     // Fragments for k-step kk+1 are read from LDS before the MFMAs of step kk issue
     // (two register sets, static indices), so LDS latency hides under 9 x 64 MFMA cycles.
     float afr[2][TPW], bfr[2];
     auto load_frag = [&](int kk, float* av, float& bv) {
-      const int kl = kk * KM + h;
-      const int py = wv * (TH / 4) + (kl >> 4), px = kl & 15;
-      bv = ds[(py * 16 + px) * MF + r];
-      const float* xrow = xs + ((py + (TPW == NTAPS ? 0 : tg)) * TW + px) * MF + r;
+      constexpr int SPR = 16 / KM;                       // k-steps per pixel row
+      const int pyo = kk / SPR, pxo = (kk % SPR) * KM;   // compile-time after unrolling
+      bv = bbase[(pyo * 16 + pxo) * MF];
 #pragma unroll
       for (int tl = 0; tl < TPW; ++tl) {
-        const int ty = (TPW == NTAPS) ? (tl / KS) : 0;  // row offset already in xrow for row groups
+        const int ty = (TPW == NTAPS) ? (tl / KS) : 0;  // row offset already in xbase for row groups
         const int tx = (TPW == NTAPS) ? (tl % KS) : tl;
-        av[tl] = xrow[(ty * TW + tx) * MF];
+        av[tl] = xbase[((pyo + ty) * TW + pxo + tx) * MF];
       }
     };
     load_frag(0, afr[0], bfr[0]);
-#pragma unroll 2
+#pragma unroll
     for (int kk = 0; kk < KSTEPS; kk += 2) {
       load_frag(kk + 1, afr[1], bfr[1]);
       __builtin_amdgcn_sched_barrier(0);  // keep the reads of step kk+1 ahead of the MFMAs of step kk
