@@ -233,3 +233,65 @@ def test_rccl_path_world1_matches_single_process(lib):
                 np.testing.assert_array_equal(wa[k], wb[k])
     finally:
         dist.destroy_process_group()
+
+
+def test_two_channel_generator_input_nicg2(lib):
+    """BASELINE configs[3] shape (FLAIR + map as generator input, GT:22, 718-722) in fp32: gen_0 is 2->32 and
+    channel 0 is still the map used for fake_y2 (GT:528)."""
+    from dep_gan_im_amd import Engine
+    from oracle import depgan_oracle as O
+    img, B = 64, 2
+    PG = O.init_generator(71, nicg=2, bias_std=0.05)
+    PD1 = O.init_critic(72, bias_std=0.05, img=img)
+    PD2 = O.init_critic(73, bias_std=0.05, img=img)
+    x, y2, z, ep = O.synth_batch(75, B, img, img, nicg=2)
+    rng = np.random.default_rng(7)
+    x = (x + 0.02 * rng.uniform(size=x.shape)).astype(np.float32)
+    y2 = (y2 + 0.02 * rng.uniform(size=y2.shape)).astype(np.float32)
+    eng = Engine(B, img, img, 2)
+    eng.set_weights("G", PG)
+    eng.set_weights("D_y2", PD1)
+    eng.set_weights("D_dem", PD2)
+    np.testing.assert_allclose(eng.g_forward(x, z).cpu().numpy(), O.g_predict(PG, x, z, nicg=2), rtol=1e-3, atol=1e-4)
+    assert srel(eng.critic("D_y2", y2, x, z, ep, update=False),
+                O.critic_grads(PD1, PG, y2, x, z, ep, "y2", nicg=2)[0]) < 1e-3
+    out = eng.generator(x, y2, z, "grads")
+    outs, g64 = O.g_grads(PG, PD1, PD2, x, y2, z, nicg=2, dtype=torch.float64)
+    _, g32 = O.g_grads(PG, PD1, PD2, x, y2, z, nicg=2, dtype=torch.float32)
+    assert srel(out, outs) < 1e-3
+    gg = eng.get_grads("G")
+    spread = max(rel(g32[k], g64[k]) for k in g64)
+    assert rel(gg["conv2d_gen_0/kernel"], g64["conv2d_gen_0/kernel"]) < max(2e-3, 3 * spread)
+    assert max(rel(gg[k], g64[k]) for k in g64) < max(2e-3, 3 * spread)
+    eng.close()
+
+
+def test_reference_schedule_one_generator_iteration(lib):
+    """schedule.train_epoch (GT:779-894) on the HIP engine vs the same schedule on the oracle closures,
+    same RNG stream: critic outputs, the ten best-of-k losses, the chosen noise and the G losses."""
+    import dep_gan_im_amd as dg
+    from dep_gan_im_amd.schedule import ScheduleState, train_epoch
+    from oracle import depgan_oracle as O
+    img, B = 64, 2
+    PG, PD1, PD2, x, y2, z, ep = _setup(img, 2 * B, 81, noisy=True)
+    nets = [dg.Gen_UNet2D((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1))]
+    for n, P in zip(nets, (PG, PD1, PD2)):
+        n.set_weights(P)
+    tr = dg.build_trainers(*nets, batchSize=B)
+    ref = O.OracleTrainers(PG, PD1, PD2, dtype=torch.float64)
+    logs = []
+    for t in (tr, ref):
+        st = ScheduleState()
+        st.gen_iterations = 26
+        log = []
+        train_epoch(t, x, y2, batchSize=B, Diters=1, state=st, rng=np.random.RandomState(5), on_gen_iteration=log.append)
+        logs.append(log)
+    a, b = logs[0][0], logs[1][0]
+    assert a["Diters"] == 1 and len(logs[0]) == 2
+    for k in ("errD_real", "errD_fake", "errD_real_dem", "errD_fake_dem"):
+        assert abs(a[k] - b[k]) < 1e-3 * (abs(b[k]) + 1e-3), k
+    np.testing.assert_allclose(a["losses_errG"], b["losses_errG"], rtol=3e-3)
+    gap = np.sort(b["losses_errG"])
+    if gap[1] - gap[0] > 6e-3 * abs(gap[0]):
+        assert a["best_noise"] == b["best_noise"]
+    assert abs(a["errG"] - b["errG"]) < 3e-3 * abs(b["errG"])
