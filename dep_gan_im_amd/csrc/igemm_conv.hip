@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
       while ((long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
     }
   }
-  unsigned long long* dbg = a.dbg ? a.dbg + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 : nullptr;
+  unsigned long long* dbg = a.dbg ? a.dbg + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 16 : nullptr;
   if (dbg && tid == 0) {
     dbg[0] = __builtin_amdgcn_s_memtime();
     dbg[6] = __builtin_amdgcn_s_memrealtime();

@@ -1169,7 +1169,7 @@ static int op_conv(const float* in, const float* w_hwio, const float* bias, floa
   return dg_conv_direct(KS, a, st);
 }
 
-// diagnostics: run the MFMA conv with per-workgroup phase stamps (8 x u64 per workgroup) into `stamps`
+// diagnostics: run the MFMA conv with per-workgroup phase stamps (16 x u64 per workgroup) into `stamps`
 int depgan_op_conv2d_stamps(const float* in, const float* w_hwio, float* out, int B, int H, int W, int Cin, int Cout,
                             int KS, unsigned long long* stamps, int reps, void* stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -8,10 +8,10 @@ def P(t): return C.c_void_p(t.data_ptr())
 def run(B,H,W,ci,co,k):
     x = torch.randn(B,H,W,ci, device=dev); w = torch.randn(k,k,ci,co, device=dev)*0.05; out = torch.empty(B,H,W,co, device=dev)
     nwg = ((H+15)//16)*((W+15)//16)*B*((co+31)//32)
-    st = torch.zeros(nwg*8, dtype=torch.int64, device=dev)
+    st = torch.zeros(nwg*16, dtype=torch.int64, device=dev)
     _lib.check(lib.depgan_op_conv2d_stamps(P(x),P(w),P(out),B,H,W,ci,co,k,P(st),3,None))
     torch.cuda.synchronize()
-    s = st.cpu().numpy().reshape(nwg,8).astype(np.int64)
+    s = st.cpu().numpy().reshape(nwg,16).astype(np.int64)
     t0 = s[:,0].min()
     dur = s[:,5]-s[:,0]
     clk = dur/np.maximum(s[:,6],1)*100.0  # MHz (realtime counter is 100 MHz)
