@@ -16,14 +16,16 @@ EXPORTS = [
     "depgan_d_forward", "depgan_critic_grads", "depgan_critic_step", "depgan_g_eval", "depgan_g_grads",
     "depgan_g_step", "depgan_apply_adam", "depgan_last_sums", "depgan_profile_enable", "depgan_profile_read",
     "depgan_profile_reset", "depgan_profile_dump", "depgan_op_conv2d", "depgan_op_conv2d_bwd_data", "depgan_op_conv2d_wgrad",
-    "depgan_op_maxpool", "depgan_op_conv2d_stamps",
+    "depgan_op_maxpool", "depgan_op_conv2d_stamps", "depgan_uresnet_grads", "depgan_uresnet_step",
+    "depgan_uresnet_eval",
 ]
 
 
 class Config(C.Structure):
     _fields_ = [("batch", C.c_int), ("height", C.c_int), ("width", C.c_int), ("nicg", C.c_int),
                 ("first_fm", C.c_int), ("im_thresh", C.c_float), ("delta", C.c_float), ("lrD", C.c_float),
-                ("lrG", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float)]
+                ("lrG", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+                ("nc_out", C.c_int)]
 
 
 NET_G, NET_D_Y2, NET_D_DEM = 0, 1, 2
@@ -77,6 +79,9 @@ def load():
     lib.depgan_op_conv2d_wgrad.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp]
     lib.depgan_op_maxpool.argtypes = [vp, vp] + [C.c_int] * 4 + [vp]
     lib.depgan_op_conv2d_stamps.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, vp]
+    lib.depgan_uresnet_grads.argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint, fp]
+    lib.depgan_uresnet_step.argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint, fp]
+    lib.depgan_uresnet_eval.argtypes = [vp, vp, vp, vp, C.c_int, fp]
     _lib = lib
     return lib
 

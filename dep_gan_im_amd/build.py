@@ -13,7 +13,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdepgan.so")
-SOURCES = ["igemm_conv.hip", "wgrad.hip", "direct.hip", "ops.hip", "noise.hip", "model.hip"]
+SOURCES = ["igemm_conv.hip", "wgrad.hip", "direct.hip", "ops.hip", "noise.hip", "train_ops.hip", "model.hip",
+           "uresnet.hip"]
 ARCH = "gfx950"
 
 

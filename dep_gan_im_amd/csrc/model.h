@@ -1,6 +1,8 @@
 // Host-side model state for the DEP-GAN hot path: parameter arenas, layer
 // tables (GT:316-345, GT:349-498), activation storage and the step drivers.
 #pragma once
+#include <string.h>
+
 #include <map>
 #include <string>
 #include <vector>
@@ -60,6 +62,10 @@ struct GLayer {
   TView din, dout;         // gradient views (dout = grad wrt out, after the producer's mask)
   TView in_mask;           // mask applied when writing din (null: none)
   Tn u;                    // FiLM pre-activation (kept when training G)
+  // learning-phase-1 path (DEP-UResNet): raw conv output and batch-statistics BN state
+  Tn raw;
+  float *bmean = nullptr, *bvar = nullptr, *bs = nullptr, *bt = nullptr, *brstd = nullptr;
+  float *cA = nullptr, *cB = nullptr, *cC = nullptr, *sums = nullptr;
   int skip_of = -1;        // pool: index of the conv layer whose output is pooled
   TView pool_dsrc;         // pool: gradient wrt the pooled tensor (raw)
   TView pool_skipgrad;     // pool: gradient arriving through the concat
@@ -132,7 +138,53 @@ struct depgan_ctx {
   float* fake_y2 = nullptr;        // [B*H*W]
   float last_sums[8];
 
+  // ---- learning-phase-1 path (nc_out == 4) ----
+  bool train_bn = false;
+  unsigned last_drop_seed = 0;
+  Tn draw_tmp;                     // gradient at the raw conv output (largest layer)
+  float *logits = nullptr, *dz = nullptr, *loss_dev = nullptr;
+  float *ones1k = nullptr, *zeros1k = nullptr;
+  float *n_mean0 = nullptr, *n_rstd0 = nullptr, *n_mean1 = nullptr, *n_rstd1 = nullptr, *n_meanh = nullptr,
+        *n_rstdh = nullptr;
+  float *n_dl = nullptr, *n_dflat = nullptr, *n_dl1 = nullptr, *n_da0 = nullptr, *n_dl0 = nullptr;
+
   // ---- profiling ----
   bool prof_on = false;
   std::vector<ProfRec> recs;
 };
+
+struct ProfScope {
+  depgan_ctx* c;
+  bool live;
+  ProfScope(depgan_ctx* c_, int klass, double flops, const char* label = "") : c(c_), live(c_->prof_on) {
+    if (!live) return;
+    ProfRec r;
+    r.klass = klass;
+    r.flops = flops;
+    strncpy(r.label, label, sizeof(r.label) - 1);
+    r.label[sizeof(r.label) - 1] = 0;
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+    hipEventRecord(r.a, c->st);
+    c->recs.push_back(r);
+  }
+  ~ProfScope() {
+    if (live) hipEventRecord(c->recs.back().b, c->st);
+  }
+};
+
+// helpers shared between model.hip and uresnet.hip
+int dmalloc(depgan_ctx* c, float** p, size_t floats);
+int talloc(depgan_ctx* c, Tn* t, int N, int H, int W, int C);
+int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS);
+void zero_ep(Epilogue* e);
+TView view_offset(TView v, long samples);
+TView strided2(TView v, int di, int dj);
+int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, int Cin, int Cout, const float* scale,
+               float* out, float* raw, int accumulate, int oi);
+int net_adam(depgan_ctx* c, Net& n);
+int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u);
+int refresh_generator(depgan_ctx* c);
+int refresh_generator_bn(depgan_ctx* c);  // phase-0 BN affines only (after the moving statistics moved)
+int uresnet_build(depgan_ctx* c);
+int uresnet_predict(depgan_ctx* c, const float* x, const float* z, float* out, int n);

@@ -48,7 +48,7 @@ float* Net::g(const std::string& name) const {
   return G + pi.off;
 }
 
-static int dmalloc(depgan_ctx* c, float** p, size_t floats) {
+int dmalloc(depgan_ctx* c, float** p, size_t floats) {
   void* q = nullptr;
   if (floats == 0) floats = 4;
   HIPCHECK(hipMalloc(&q, floats * sizeof(float)));
@@ -57,7 +57,7 @@ static int dmalloc(depgan_ctx* c, float** p, size_t floats) {
   *p = (float*)q;
   return DG_OK;
 }
-static int talloc(depgan_ctx* c, Tn* t, int N, int H, int W, int C) {
+int talloc(depgan_ctx* c, Tn* t, int N, int H, int W, int C) {
   t->H = H;
   t->W = W;
   t->C = C;
@@ -75,27 +75,8 @@ static int net_alloc(depgan_ctx* c, Net* n) {
 // ---------------------------------------------------------------------------
 // profiling helpers
 // ---------------------------------------------------------------------------
-struct ProfScope {
-  depgan_ctx* c;
-  bool live;
-  ProfScope(depgan_ctx* c_, int klass, double flops, const char* label = "") : c(c_), live(c_->prof_on) {
-    if (!live) return;
-    ProfRec r;
-    r.klass = klass;
-    r.flops = flops;
-    strncpy(r.label, label, sizeof(r.label) - 1);
-    r.label[sizeof(r.label) - 1] = 0;
-    hipEventCreate(&r.a);
-    hipEventCreate(&r.b);
-    hipEventRecord(r.a, c->st);
-    c->recs.push_back(r);
-  }
-  ~ProfScope() {
-    if (live) hipEventRecord(c->recs.back().b, c->st);
-  }
-};
 
-static int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
+int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
   const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cin * a.Cout * KS * KS;
   char lb[56];
   snprintf(lb, sizeof(lb), "conv k%d b%d %dx%d %d->%d", KS, a.B, a.H, a.W, a.Cin, a.Cout);
@@ -107,16 +88,16 @@ static int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int
   return dg_conv_direct(KS, a, c->st);
 }
 
-static void zero_ep(Epilogue* e) {
+void zero_ep(Epilogue* e) {
   memset(e, 0, sizeof(*e));
   e->out_pre = e->res = e->mask = null_view();
 }
 
-static TView view_offset(TView v, long samples) {
+TView view_offset(TView v, long samples) {
   v.p += samples * v.sB;
   return v;
 }
-static TView strided2(TView v, int di, int dj) {  // pixel grid (2i+di, 2j+dj)
+TView strided2(TView v, int di, int dj) {  // pixel grid (2i+di, 2j+dj)
   TView r = v;
   r.p = v.p + di * v.sY + dj * v.sX;
   r.sY = 2 * v.sY;
@@ -125,7 +106,7 @@ static TView strided2(TView v, int di, int dj) {  // pixel grid (2i+di, 2j+dj)
 }
 
 // weight gradient: slabs + reduction (+ optional BN scale / raw copy / OI layout)
-static int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, int Cin, int Cout,
+int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, int Cin, int Cout,
                       const float* scale, float* out, float* raw, int accumulate, int oi) {
   WgradArgs a;
   a.x = x;
@@ -208,7 +189,7 @@ static int build_generator(depgan_ctx* c) {
   size_t bnch = 2 * fm + 32 * fm;  // BN channels so far
   for (int i = 0; i < kNTrunk; ++i) {
     const TrunkEnt& e = kTrunk[i];
-    const int ci = e.ci < 0 ? c->cfg.nicg : e.ci * fm, co = e.co < 0 ? 1 : e.co * fm;
+    const int ci = e.ci < 0 ? c->cfg.nicg : e.ci * fm, co = e.co < 0 ? c->cfg.nc_out : e.co * fm;
     if (e.kind == G_CONV || e.kind == G_FILM) {
       g.add(std::string("conv2d_") + e.name + "/kernel", {3, 3, ci, co}, true);
       g.add(std::string("conv2d_") + e.name + "/bias", {co}, true);
@@ -300,7 +281,7 @@ static int build_generator(depgan_ctx* c) {
     L.kind = e.kind;
     L.name = e.name;
     L.Cin = e.ci < 0 ? c->cfg.nicg : e.ci * fm;
-    L.Cout = e.co < 0 ? 1 : e.co * fm;
+    L.Cout = e.co < 0 ? c->cfg.nc_out : e.co * fm;
     L.H = H;
     L.W = W;
     L.in = cur;
@@ -397,7 +378,7 @@ static int build_generator(depgan_ctx* c) {
     } else if (e.kind == G_HEAD) {
       L.Wt = g.p(std::string(e.name) + "/kernel"); L.b = g.p(std::string(e.name) + "/bias");
       L.dW = g.g(std::string(e.name) + "/kernel"); L.db = g.g(std::string(e.name) + "/bias");
-      DGCHECK(talloc(c, &c->attr, B, H, W, 1));
+      DGCHECK(talloc(c, &c->attr, B, H, W, c->cfg.nc_out));
       L.out = c->attr.view();
     }
     producer = i;
@@ -489,7 +470,7 @@ static int build_critics(depgan_ctx* c) {
 // ---------------------------------------------------------------------------
 // derived state (BN affines, packed weights)
 // ---------------------------------------------------------------------------
-static int refresh_generator(depgan_ctx* c) {
+int refresh_generator_bn(depgan_ctx* c) {
   Net& g = c->g;
   const float eps = 1e-3f;  // keras BatchNormalization default
   NoiseParams& np = c->np;
@@ -510,16 +491,27 @@ static int refresh_generator(depgan_ctx* c) {
   }
   for (size_t i = 0; i < c->gl.size(); ++i) {
     GLayer& L = c->gl[i];
+    if (L.kind == G_CONV || L.kind == G_FILM || L.kind == G_DECONV)
+      DGCHECK(dg_bn_prepare(L.gamma, L.beta, L.mean, L.var, eps, L.s, L.t, L.rstd, L.Cout, c->st));
+  }
+  return DG_OK;
+}
+
+int refresh_generator(depgan_ctx* c) {
+  DGCHECK(refresh_generator_bn(c));
+  for (size_t i = 0; i < c->gl.size(); ++i) {
+    GLayer& L = c->gl[i];
+    // backward packs carry the phase-0 BN scale; the learning-phase-1 path differentiates through the batch
+    // statistics instead and needs them unscaled
+    const float* ks = c->train_bn ? nullptr : L.s;
     if (L.kind == G_CONV || L.kind == G_FILM) {
-      DGCHECK(dg_bn_prepare(L.gamma, L.beta, L.mean, L.var, eps, L.s, L.t, L.rstd, L.Cout, c->st));
       if (L.wpf[0]) DGCHECK(dg_pack_weights(L.pf, L.Wt, L.Cin, L.Cout, 0, 0, 0, nullptr, L.wpf[0], c->st));
-      if (L.wpb[0]) DGCHECK(dg_pack_weights(L.pb, L.Wt, L.Cin, L.Cout, 0, 1, 1, L.s, L.wpb[0], c->st));
+      if (L.wpb[0]) DGCHECK(dg_pack_weights(L.pb, L.Wt, L.Cin, L.Cout, 0, 1, 1, ks, L.wpb[0], c->st));
     } else if (L.kind == G_DECONV) {
-      DGCHECK(dg_bn_prepare(L.gamma, L.beta, L.mean, L.var, eps, L.s, L.t, L.rstd, L.Cout, c->st));
       for (int t = 0; t < 4; ++t) {
         const float* src = L.Wt + (size_t)t * L.Cout * L.Cin;  // (kh,kw,Cout,Cin)
         DGCHECK(dg_pack_weights(L.pf, src, L.Cin, L.Cout, 1, 0, 0, nullptr, L.wpf[t], c->st));
-        DGCHECK(dg_pack_weights(L.pb, src, L.Cin, L.Cout, 1, 1, 0, L.s, L.wpb[t], c->st));
+        DGCHECK(dg_pack_weights(L.pb, src, L.Cin, L.Cout, 1, 1, 0, ks, L.wpb[t], c->st));
       }
     }
   }
@@ -527,6 +519,7 @@ static int refresh_generator(depgan_ctx* c) {
 }
 
 static int refresh_critic(depgan_ctx* c, DNet& D) {
+  if (c->dl.empty()) return DG_OK;  // supervised context: no critics
   for (int l = 0; l < 11; ++l) {
     const DLayer& L = c->dl[l];
     if (D.wpf[l]) DGCHECK(dg_pack_weights(L.pf, D.W[l], L.Cin, L.Cout, 0, 0, 0, nullptr, D.wpf[l], c->st));
@@ -538,7 +531,7 @@ static int refresh_critic(depgan_ctx* c, DNet& D) {
 // ---------------------------------------------------------------------------
 // generator forward / backward
 // ---------------------------------------------------------------------------
-static int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u) {
+int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u) {
   {
     ProfScope ps(c, 2, 0.0);
     DGCHECK(dg_noise_fwd(c->np, z, c->na, n, c->st));
@@ -582,7 +575,7 @@ static int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool 
         a.w = L.wpf[t];
         DGCHECK(conv_launch(c, L.pf, a, 1));
       }
-    } else if (L.kind == G_HEAD) {
+    } else if (L.kind == G_HEAD && c->cfg.nc_out == 1) {
       ProfScope ps(c, 2, 0.0);
       DGCHECK(dg_head_fwd(L.in.p, L.Wt, L.b, c->attr.p, (long)n * L.H * L.W, L.Cin, 1, c->st));
     }
@@ -617,7 +610,7 @@ static int g_conv_bn_bwd(depgan_ctx* c, GLayer& L, size_t li, const float* x_use
   return conv_launch(c, L.pb, a, 3);
 }
 
-static int g_backward(depgan_ctx* c, const float* x, const float* z, int n) {
+int g_backward(depgan_ctx* c, const float* x, const float* z, int n) {
   for (int i = (int)c->gl.size() - 1; i >= 0; --i) {
     GLayer& L = c->gl[i];
     if (L.kind == G_HEAD) {
@@ -767,7 +760,7 @@ static int d_backward_chain(depgan_ctx* c, DNet& D, long s0, int N, const float*
   return DG_OK;
 }
 
-static int net_adam(depgan_ctx* c, Net& n) {
+int net_adam(depgan_ctx* c, Net& n) {
   n.adam_t += 1;
   const double b1 = c->cfg.beta1, b2 = c->cfg.beta2;
   const double t = (double)n.adam_t;
@@ -781,6 +774,7 @@ static int net_adam(depgan_ctx* c, Net& n) {
 // ---------------------------------------------------------------------------
 static int critic_grads(depgan_ctx* c, int which, const float* y2, const float* x, const float* z, const float* ep,
                         float out[2]) {
+  if (c->cfg.nc_out != 1) { dg_set_error("the WGAN-GP closures need nc_out == 1"); return DG_ERR_ARG; }
   DNet& D = c->d[which];
   const int B = c->cfg.batch, H0 = c->cfg.height, W0 = c->cfg.width;
   const long HW0 = (long)H0 * W0;
@@ -861,6 +855,7 @@ static int critic_grads(depgan_ctx* c, int which, const float* y2, const float* 
 }
 
 static int g_eval_impl(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6], bool train) {
+  if (c->cfg.nc_out != 1) { dg_set_error("the WGAN-GP closures need nc_out == 1"); return DG_ERR_ARG; }
   const int B = c->cfg.batch, H0 = c->cfg.height, W0 = c->cfg.width;
   const long HW0 = (long)H0 * W0, P = (long)B * HW0;
   DGCHECK(g_forward(c, x, z, B, train));
@@ -935,9 +930,17 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
   }
   depgan_ctx* c = new depgan_ctx();
   c->cfg = *cfg;
+  if (c->cfg.nc_out <= 0) c->cfg.nc_out = 1;
+  if (c->cfg.nc_out != 1 && c->cfg.nc_out != 4) {
+    dg_set_error("depgan_create: nc_out must be 1 (DEP-GAN) or 4 (DEP-UResNet)");
+    delete c;
+    return DG_ERR_ARG;
+  }
+  c->train_bn = c->cfg.nc_out != 1;
   memset(c->last_sums, 0, sizeof(c->last_sums));
   int rc = build_generator(c);
-  if (rc == DG_OK) rc = build_critics(c);
+  if (rc == DG_OK && !c->train_bn) rc = build_critics(c);   // the supervised path has no critics
+  if (rc == DG_OK && c->train_bn) rc = uresnet_build(c);
   if (rc == DG_OK) {
     // slab workspace: the largest weight-gradient call of either network
     size_t mx = 0;
@@ -948,11 +951,11 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
       if (L.kind == G_CONV || L.kind == G_FILM)
         f = (L.Cin >= 8) ? dg_wgrad_part_floats(3, B, L.H, L.W, L.Cin, L.Cout)
                          : dg_wgrad_small_part_floats(3, B, L.H, L.W, L.Cin, L.Cout);
-      else if (L.kind == G_DECONV)
+      else if (L.kind == G_DECONV || (L.kind == G_HEAD && c->train_bn))
         f = dg_wgrad_part_floats(1, B, L.H, L.W, L.Cin, L.Cout);
       if (f > mx) mx = f;
     }
-    for (int l = 0; l < 11; ++l) {
+    for (size_t l = 0; l < c->dl.size(); ++l) {
       const DLayer& L = c->dl[l];
       const size_t f = (L.Cin >= 8) ? dg_wgrad_part_floats(L.KS, 3 * B, L.H, L.W, L.Cin, L.Cout)
                                     : dg_wgrad_small_part_floats(L.KS, 3 * B, L.H, L.W, L.Cin, L.Cout);
@@ -1039,6 +1042,7 @@ int depgan_weights_changed(depgan_ctx* c, int net) {
 
 int depgan_g_forward(depgan_ctx* c, const float* x, const float* z, float* out, int n) {
   if (n < 1 || n > c->cfg.batch) { dg_set_error("g_forward: n must be in [1, batch]"); return DG_ERR_ARG; }
+  if (c->cfg.nc_out != 1) return uresnet_predict(c, x, z, out, n);
   DGCHECK(g_forward(c, x, z, n, false));
   HIPCHECK(hipMemcpyAsync(out, c->attr.p, (size_t)n * c->cfg.height * c->cfg.width * sizeof(float),
                           hipMemcpyDeviceToDevice, c->st));

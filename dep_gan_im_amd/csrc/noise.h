@@ -31,3 +31,7 @@ int dg_noise_fwd(const NoiseParams& P, const float* z, NoiseActs A, int B, hipSt
 // scratch: 4*B*1024 floats
 int dg_noise_bwd(const NoiseParams& P, const NoiseGrads& G, const float* z, NoiseActs A, const float* dheads,
                  float* scratch, int B, hipStream_t st);
+
+int dg_noise_heads_lin(const NoiseParams& P, const float* flat, float* lin, float* heads, int B, hipStream_t st);
+int dg_noise_heads_bwd_lin(const NoiseParams& P, const NoiseGrads& G, const float* flat, const float* dl, float* dflat,
+                           int B, hipStream_t st);

@@ -219,3 +219,20 @@ int dg_noise_bwd(const NoiseParams& P, const NoiseGrads& G, const float* z, Nois
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
+
+// ---- pieces reused by the training-mode (batch-statistics) noise MLP ----
+// lin[b][j] = flat[b] . Wh[:, j] + bh[j]   (P.sh / P.th must point at ones / zeros so the affine is the identity)
+int dg_noise_heads_lin(const NoiseParams& P, const float* flat, float* lin, float* heads, int B, hipStream_t st) {
+  hipLaunchKernelGGL(noise_heads_fwd_kernel, dim3(B, 4), dim3(256), 0, st, P, flat, lin, heads);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+// dWh = flat^T dl ; dflat = dl Wh^T
+int dg_noise_heads_bwd_lin(const NoiseParams& P, const NoiseGrads& G, const float* flat, const float* dl, float* dflat,
+                           int B, hipStream_t st) {
+  hipLaunchKernelGGL(noise_heads_bwd_w, dim3(4, 1024), dim3(256), 0, st, P, G, flat, dl, B);
+  HIPCHECK(hipGetLastError());
+  hipLaunchKernelGGL(noise_heads_bwd_flat, dim3(B, 4), dim3(256), 0, st, P, dl, dflat);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}

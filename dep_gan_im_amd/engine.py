@@ -26,15 +26,16 @@ def _torch():
 
 class Engine:
     def __init__(self, batch, height=256, width=256, nicg=1, first_fm=32, im_thresh=0.5, delta=10.0, lrD=1e-4,
-                 lrG=1e-4, beta1=0.0, beta2=0.9, adam_eps=1e-7, device=None):
+                 lrG=1e-4, beta1=0.0, beta2=0.9, adam_eps=1e-7, device=None, nc_out=1):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.DepganError("dep_gan_im_amd needs a ROCm GPU (MI355X): torch.cuda.is_available() is False")
         self.lib = load()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         torch.cuda.set_device(self.device)
-        self.cfg = Config(batch, height, width, nicg, first_fm, im_thresh, delta, lrD, lrG, beta1, beta2, adam_eps)
-        self.batch, self.height, self.width, self.nicg = batch, height, width, nicg
+        self.cfg = Config(batch, height, width, nicg, first_fm, im_thresh, delta, lrD, lrG, beta1, beta2, adam_eps,
+                          nc_out)
+        self.batch, self.height, self.width, self.nicg, self.nc_out = batch, height, width, nicg, nc_out
         h = C.c_void_p()
         check(self.lib.depgan_create(C.byref(self.cfg), C.byref(h)), "depgan_create")
         self.h = h
@@ -161,7 +162,7 @@ class Engine:
         if z.shape[1] != 32:
             raise ValueError("noise input must be (N,32,1)")
         n = x.shape[0]
-        out = torch.empty((n, self.height, self.width, 1), dtype=torch.float32, device=self.device)
+        out = torch.empty((n, self.height, self.width, self.nc_out), dtype=torch.float32, device=self.device)
         self._use_current_stream()
         for i in range(0, n, self.batch):
             m = min(self.batch, n - i)
@@ -213,6 +214,30 @@ class Engine:
         fn = {"eval": self.lib.depgan_g_eval, "grads": self.lib.depgan_g_grads, "step": self.lib.depgan_g_step}[mode]
         check(fn(self.h, self._p(x), self._p(y2), self._p(z), out), "generator " + mode)
         return [float(v) for v in out]
+
+    # ---- DEP-UResNet supervised path (nc_out = 4) ----
+    def uresnet(self, x, z, labels, mode="step", drop_seed=0):
+        """mode 'step' = train_on_batch (UT:602-606), 'grads' = gradients only, 'eval' = phase-0 loss.
+        The leading dimension may be shorter than the engine batch (Keras' last batch of an epoch)."""
+        x = self._dev(x)
+        n = int(x.shape[0])
+        if n < 1 or n > self.batch or tuple(x.shape[1:]) != (self.height, self.width, self.nicg):
+            raise ValueError("images must be (n<=%d,%d,%d,%d), got %s" % (self.batch, self.height, self.width,
+                                                                          self.nicg, tuple(x.shape)))
+        labels = self._dev(labels, (n, self.height, self.width, self.nc_out))
+        z = self._dev(z).reshape(-1)
+        if z.numel() != n * 32:
+            raise ValueError("noise must be (%d,32,1)" % n)
+        loss = C.c_float()
+        self._use_current_stream()
+        if mode == "eval":
+            check(self.lib.depgan_uresnet_eval(self.h, self._p(x), self._p(z), self._p(labels), n, C.byref(loss)),
+                  "depgan_uresnet_eval")
+        else:
+            fn = {"step": self.lib.depgan_uresnet_step, "grads": self.lib.depgan_uresnet_grads}[mode]
+            check(fn(self.h, self._p(x), self._p(z), self._p(labels), n, C.c_uint(int(drop_seed) & 0xFFFFFFFF),
+                     C.byref(loss)), "depgan_uresnet_" + mode)
+        return float(loss.value)
 
     def apply_adam(self, net):
         self._use_current_stream()

@@ -200,6 +200,13 @@ def _gen_static_table(nicg, fm, nc_out):
     return T
 
 
+class History:
+    """keras.callbacks.History: .history['loss'] / ['val_loss'] per epoch (UT:609-618)."""
+
+    def __init__(self, history):
+        self.history = history
+
+
 class GeneratorModel(_Model):
     net = "G"
     name = "Gen_UNet2D"
@@ -208,24 +215,118 @@ class GeneratorModel(_Model):
         super().__init__(input_shape, seed)
         if tuple(noiseZ_shape) != (32, 1) or first_fm != 32:
             raise ValueError("the HIP path is built for noiseZ_shape=(32,1), first_fm=32 (GT:520)")
-        if nc_out != 1:
-            raise NotImplementedError("nc_out != 1 (DEP-UResNet softmax head) is not built yet")
+        if nc_out not in (1, 4):
+            raise ValueError("nc_out must be 1 (DEP-GAN generator, GT:520) or 4 (DEP-UResNet, UT:583)")
         self.noiseZ_shape, self.first_fm, self.nc_out = tuple(noiseZ_shape), first_fm, nc_out
+        if nc_out != 1:
+            self.name = "DEP_UResNet"
+        # Gen_UNet2D compiles the softmax variant itself: Adam(lr=1e-4), categorical cross-entropy (UT:427)
+        self._lr = 1e-4
+        self._drop_rng = np.random.RandomState(seed)
 
     def _static_table(self):
         return _gen_static_table(self.input_shape[2], self.first_fm, self.nc_out)
 
     def _spec_engine(self, batch):
         H, W, nicg = self.input_shape
-        return Engine(batch, H, W, nicg)
+        if self.nc_out == 1:
+            return Engine(batch, H, W, nicg)
+        return Engine(batch, H, W, nicg, lrG=self._lr, beta1=0.9, beta2=0.999, nc_out=self.nc_out)
 
     def predict(self, inputs, batch_size=32):
-        """netG.predict([x, z])  (GT:848, 859; GE:621)."""
+        """netG.predict([x, z])  (GT:848, 859; GE:621; UE:  my_network.predict)."""
         if not isinstance(inputs, (list, tuple)) or len(inputs) != 2:
             raise ValueError("Gen_UNet2D.predict expects [images, noise]")
         x, z = inputs
         eng = self._ensure_engine(min(batch_size, max(1, len(x))))
         return eng.g_forward(x, z).cpu().numpy()
+
+    # ---- supervised surface of the softmax variant (DEP-UResNet, UT:427, 583-618) ----
+    def _need_softmax(self, what):
+        if self.nc_out == 1:
+            raise RuntimeError("%s: the tanh generator is trained through the WGAN-GP closures "
+                               "(trainers.build_trainers), not compiled with a loss" % what)
+
+    def compile(self, optimizer="adam", loss="categorical_crossentropy", lr=None, **_):
+        """model.compile(optimizer=Adam(lr=1e-4), loss='categorical_crossentropy')  (UT:427)."""
+        self._need_softmax("compile")
+        if loss != "categorical_crossentropy":
+            raise ValueError("only loss='categorical_crossentropy' is built (UT:427)")
+        if lr is None:
+            lr = getattr(optimizer, "lr", None)
+        if lr is not None:
+            if self._engine is not None and float(lr) != self._lr:
+                raise RuntimeError("compile(lr=...) must come before the first fit / train_on_batch / predict")
+            self._lr = float(lr)
+        return self
+
+    def _next_drop_seed(self):
+        return int(self._drop_rng.randint(1, 2 ** 31 - 1))
+
+    def train_on_batch(self, inputs, labels, drop_seed=None):
+        """One learning-phase-1 Adam step; returns the batch loss."""
+        self._need_softmax("train_on_batch")
+        x, z = inputs
+        eng = self._ensure_engine(len(x))
+        return eng.uresnet(x, z, labels, "step", self._next_drop_seed() if drop_seed is None else drop_seed)
+
+    def test_on_batch(self, inputs, labels):
+        self._need_softmax("test_on_batch")
+        x, z = inputs
+        return self._ensure_engine(len(x)).uresnet(x, z, labels, "eval")
+
+    def evaluate(self, inputs, labels, batch_size=32, verbose=0):
+        """Sample-weighted mean of the phase-0 loss over batches (keras Model.evaluate)."""
+        self._need_softmax("evaluate")
+        x, z = inputs
+        eng = self._ensure_engine(min(batch_size, len(x)))
+        bs = min(batch_size, eng.batch)
+        tot = 0.0
+        for i in range(0, len(x), bs):
+            m = min(bs, len(x) - i)
+            tot += m * eng.uresnet(x[i:i + m], z[i:i + m], labels[i:i + m], "eval")
+        return tot / len(x)
+
+    def fit(self, inputs, labels, epochs=1, batch_size=32, shuffle=True, validation_data=None, verbose=1,
+            print_fn=print):
+        """my_network.fit([flair, noise], onehot, epochs=1, batch_size=nb_samples, shuffle=..., validation_data=...)
+        (UT:602-606).  Batches in index order (after an optional np.random shuffle, as keras does), a short last
+        batch, per-epoch loss = sample-weighted mean of the batch losses; returns an object with .history."""
+        self._need_softmax("fit")
+        x, z = inputs
+        n = len(x)
+        if len(z) != n or len(labels) != n:
+            raise ValueError("fit: images, noise and labels must have the same length")
+        eng = self._ensure_engine(min(batch_size, n))
+        bs = min(batch_size, eng.batch)
+        hist = {"loss": []}
+        if validation_data is not None:
+            hist["val_loss"] = []
+        for ep in range(epochs):
+            order = np.arange(n)
+            if shuffle:
+                np.random.shuffle(order)
+            tot = 0.0
+            for i in range(0, n, bs):
+                idx = order[i:i + bs]
+                tot += len(idx) * eng.uresnet(x[idx], z[idx], labels[idx], "step", self._next_drop_seed())
+            hist["loss"].append(tot / n)
+            msg = "Epoch %d/%d - loss: %.4f" % (ep + 1, epochs, hist["loss"][-1])
+            if validation_data is not None:
+                (vx, vz), vy = validation_data
+                hist["val_loss"].append(self.evaluate([vx, vz], vy, batch_size=bs))
+                msg += " - val_loss: %.4f" % hist["val_loss"][-1]
+            if verbose:
+                print_fn(msg)
+        return History(hist)
+
+    def get_config(self):
+        return {"name": self.name, "input_shape": self.input_shape, "noiseZ_shape": self.noiseZ_shape,
+                "first_fm": self.first_fm, "nc_out": self.nc_out}
+
+    def to_json(self):
+        import json
+        return json.dumps(self.get_config())
 
 
 _DIS = [("dis_0a", 5, 1, 16), ("dis_0b", 5, 16, 16), ("dis_1a", 5, 16, 32), ("dis_1b", 5, 32, 32),

@@ -30,6 +30,8 @@ typedef struct depgan_config {
   float delta;      /* WGAN-GP weight (GT:37)                                          */
   float lrD, lrG;   /* GT:44-45                                                        */
   float beta1, beta2, adam_eps; /* Adam(beta_1=0, beta_2=0.9), K.epsilon() (GT:549)    */
+  int nc_out;       /* generator head channels: 1 = DEP-GAN (tanh, GT:520); 4 = DEP-UResNet (softmax, UT:583).
+                       0 is read as 1.                                                    */
 } depgan_config;
 
 enum { DEPGAN_NET_G = 0, DEPGAN_NET_D_Y2 = 1, DEPGAN_NET_D_DEM = 2 };
@@ -71,6 +73,21 @@ int depgan_g_eval(depgan_ctx* ctx, const float* x_dev, const float* y2_dev, cons
 int depgan_g_grads(depgan_ctx* ctx, const float* x_dev, const float* y2_dev, const float* z_dev, float out_host[6]);
 int depgan_g_step(depgan_ctx* ctx, const float* x_dev, const float* y2_dev, const float* z_dev, float out_host[6]);
 int depgan_apply_adam(depgan_ctx* ctx, int net);
+
+/* DEP-UResNet supervised path (DEP-UResNet-wNoises-training-4fold.py "UT"; contexts created with nc_out = 4):
+ * my_network.fit / train_on_batch (UT:427, 602-606) = learning phase 1: batch-statistics BatchNorm with
+ * moving-average updates, Dropout(0.25) after conv_10 (UT:388; drop_seed 0 disables it), softmax +
+ * categorical cross-entropy, Adam(beta1, beta2 of the config).  labels: one-hot (n,H,W,4) fp32.
+ * n: samples in this call (1..batch; the last batch of a keras epoch may be short); loss_host: mean loss.
+ * depgan_uresnet_grads leaves the gradients in the G arena and, like any phase-1 forward pass, moves
+ * the BN moving statistics; depgan_uresnet_step also applies Adam.                                   */
+int depgan_uresnet_grads(depgan_ctx* ctx, const float* x_dev, const float* z_dev, const float* labels_dev, int n,
+                         unsigned drop_seed, float* loss_host);
+int depgan_uresnet_step(depgan_ctx* ctx, const float* x_dev, const float* z_dev, const float* labels_dev, int n,
+                        unsigned drop_seed, float* loss_host);
+/* validation loss in learning phase 0 (UT:606); n in 1..batch */
+int depgan_uresnet_eval(depgan_ctx* ctx, const float* x_dev, const float* z_dev, const float* labels_dev, int n,
+                        float* loss_host);
 
 /* Un-normalised pieces of the last critic / generator evaluation, for exact
  * data-parallel reporting: critic: [sum D(real), sum D(fake), sum (norm-1)^2, n];

@@ -472,3 +472,157 @@ def synth_batch(seed, B, H=256, W=256, nicg=1):
     ep = rng.uniform(size=(B, 1, 1, 1))
     return (x.astype(np.float32), y2[..., None].astype(np.float32),
             z.astype(np.float32), ep.astype(np.float32))
+
+
+# ----------------------------------------------------------------------------
+# DEP-UResNet supervised path (reference
+# /root/reference/DEP-UResNet-wNoises-training-4fold.py, "UT")
+#   same Gen_UNet2D with ONE Dropout(0.25) after conv_10 (UT:388), nc_out = 4 + softmax (UT:424),
+#   compile(Adam(1e-4), 'categorical_crossentropy') (UT:427), trained with Model.fit (UT:602-606):
+#   learning phase 1 => batch-statistics BatchNorm + moving-average updates, active Dropout.
+# ----------------------------------------------------------------------------
+BN_MOMENTUM = 0.99     # keras default (UT:26 defines bn_momentum but never passes it)
+DROP_RATE = 0.25
+
+
+def hash_uniform_u32(seed, n):
+    """Counter-based RNG shared bit-for-bit with the HIP kernel (murmur3 finaliser of index*golden ^ seed)."""
+    i = np.arange(n, dtype=np.uint64)
+    x = ((i * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) ^ np.uint64(seed & 0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
+
+
+def dropout_keep_mask(seed, shape_nhwc, rate=DROP_RATE):
+    """keep[b,h,w,c] in {0,1}: element dropped when hash < rate * 2^32 (NHWC linear index)."""
+    n = int(np.prod(shape_nhwc))
+    thr = np.uint32(int(rate * 4294967296.0))
+    return (hash_uniform_u32(seed, n) >= thr).reshape(shape_nhwc)
+
+
+def _bn_train(x, T, name, ch_axis, stats):
+    """phase-1 BN: batch mean / biased variance over all non-channel axes (App. B.3)."""
+    axes = [a for a in range(x.dim()) if a != ch_axis]
+    mean = x.mean(dim=axes)
+    var = x.var(dim=axes, unbiased=False)
+    shape = [1] * x.dim()
+    shape[ch_axis] = -1
+    y = (x - mean.view(shape)) * torch.rsqrt(var.view(shape) + BN_EPS) * T[name + "/gamma"].view(shape) \
+        + T[name + "/beta"].view(shape)
+    if stats is not None:
+        n = x.numel() // x.shape[ch_axis]
+        stats[name] = (mean.detach(), var.detach(), n, x.dim() == 4)
+    return y
+
+
+def uresnet_forward_t(T, x, z, phase=1, keep_mask=None, stats=None, fm=32, nc_out=4):
+    """DEP-UResNet forward.  x (B,H,W,1), z (B,32,1); keep_mask: NHWC {0,1} mask for do_gen_1 (phase 1).
+    Returns softmax probabilities (B,H,W,nc_out)."""
+    def bn(v, name, ch_axis=1):
+        return _bn_train(v, T, name, ch_axis, stats) if phase == 1 else _bn_infer(v, T, name, ch_axis)
+
+    h = z @ T["dense_noise_1_add_f0/kernel"] + T["dense_noise_1_add_f0/bias"]
+    h = torch.relu(bn(h, "dense_bn_noise_1_add_f0", 2))
+    h = h @ T["dense_noise_1_add_f1/kernel"] + T["dense_noise_1_add_f1/bias"]
+    h = torch.relu(bn(h, "dense_bn_noise_1_add_f1", 2))
+    flat = h.reshape(h.shape[0], -1)
+    heads = {}
+    for sfx, _ in NOISE_HEADS:
+        n = "noise_2_" + sfx
+        heads[n] = bn(flat @ T["dense_" + n + "/kernel"] + T["dense_" + n + "/bias"], "dense_bn_" + n, 1)
+    a = _nchw(x)
+    skips = {}
+    for ent in gen_trunk(1, fm, nc_out):
+        kind, name = ent[0], ent[1]
+        if kind == "conv":
+            a = torch.relu(bn(_conv_same(a, T["conv2d_" + name + "/kernel"], T["conv2d_" + name + "/bias"]), "bn_" + name))
+            if name == "gen_10" and phase == 1 and keep_mask is not None:      # do_gen_1, UT:388
+                a = a * _nchw(keep_mask.to(a.dtype)) / (1.0 - DROP_RATE)
+        elif kind == "film":
+            mul_n, add_n = film_names(ent[4])
+            u = bn(_conv_same(a, T["conv2d_" + name + "/kernel"], T["conv2d_" + name + "/bias"]), "bn_" + name)
+            a = torch.relu(u * heads[mul_n][:, :, None, None] + heads[add_n][:, :, None, None]) + a
+        elif kind == "pool":
+            skips[name] = a
+            a = F.max_pool2d(a, 2)
+        elif kind == "deconv":
+            w = T["deconv2d_" + name + "/kernel"]
+            a = F.conv_transpose2d(a, w.permute(3, 2, 0, 1), T["deconv2d_" + name + "/bias"], stride=2)
+            a = torch.relu(bn(a, "bn_" + name))
+            a = torch.cat([a, skips[ent[4]]], dim=1)
+        elif kind == "head":
+            a = torch.softmax(_conv_same(a, T[name + "/kernel"], T[name + "/bias"]), dim=1)
+    return _nhwc(a)
+
+
+def keras_categorical_crossentropy_t(p, t):
+    """keras.losses.categorical_crossentropy on probabilities (App. B.9): renormalise, clip, -sum t log p, mean."""
+    p = p / p.sum(dim=-1, keepdim=True)
+    p = torch.clamp(p, 1e-7, 1.0 - 1e-7)
+    return (-(t * torch.log(p)).sum(dim=-1)).mean()
+
+
+def uresnet_predict(P, x, z, dtype=torch.float32):
+    with torch.no_grad():
+        return uresnet_forward_t(to_torch(P, dtype), _t(x, dtype), _t(z, dtype), phase=0).numpy()
+
+
+def uresnet_grads(P, x, z, labels, drop_seed=None, dtype=torch.float32):
+    """One Model.train_on_batch worth of gradients (phase 1).  labels: one-hot (B,H,W,4).
+    Returns (loss, grads dict, batch BN stats dict)."""
+    T = to_torch(P, dtype, requires_grad=True)
+    xt, zt, lt = _t(x, dtype), _t(z, dtype), _t(np.asarray(labels, np.float32), dtype)
+    keep = None
+    if drop_seed is not None:
+        B, H, W, _ = xt.shape
+        keep = torch.tensor(dropout_keep_mask(drop_seed, (B, H // 4, W // 4, 96)))
+    stats = {}
+    p = uresnet_forward_t(T, xt, zt, phase=1, keep_mask=keep, stats=stats)
+    loss = keras_categorical_crossentropy_t(p, lt)
+    names = trainable_names(P)
+    gs = torch.autograd.grad(loss, [T[n] for n in names], allow_unused=True)
+    grads = {n: (g.detach().numpy() if g is not None else np.zeros_like(P[n])) for n, g in zip(names, gs)}
+    return float(loss.detach()), grads, stats
+
+
+class OracleUResNet:
+    """my_network.train_on_batch / fit step (UT:427, 602-606): Adam(1e-4, .9, .999) + BN moving averages."""
+
+    def __init__(self, P, lr=1e-4, dtype=torch.float32):
+        self.P, self.dtype = P, dtype
+        self.opt = KerasAdam(trainable_names(P), lr, 0.9, 0.999)
+
+    def train_on_batch(self, inputs, labels, drop_seed=None):
+        x, z = inputs
+        loss, grads, stats = uresnet_grads(self.P, x, z, labels, drop_seed, self.dtype)
+        self.opt.apply(self.P, grads)
+        for name, (mean, var, n, fused) in stats.items():
+            # moving variance: Bessel-corrected on the fused 4-D path, n/(n-(1+eps)) on the generic path
+            corr = n / (n - 1.0) if fused else n / (n - (1.0 + BN_EPS))
+            mm, mv = self.P[name + "/moving_mean"], self.P[name + "/moving_variance"]
+            self.P[name + "/moving_mean"] = (mm * BN_MOMENTUM + mean.numpy() * (1 - BN_MOMENTUM)).astype(mm.dtype)
+            self.P[name + "/moving_variance"] = (mv * BN_MOMENTUM + var.numpy() * corr * (1 - BN_MOMENTUM)).astype(mv.dtype)
+        return loss
+
+    def predict(self, inputs):
+        return uresnet_predict(self.P, inputs[0], inputs[1], self.dtype)
+
+
+def synth_uresnet_batch(seed, B, H=256, W=256, thr=0.178):
+    """z-scored FLAIR-like slice, labels {0,1,2,3} from thresholding x0 / y2
+    (1 shrink, 2 grow, 3 stay; coding per GE:722-741), one-hot (B,H,W,4) (UT:565-568)."""
+    x0, y2, z, _ = synth_batch(seed, B, H, W)
+    rng = np.random.default_rng(seed + 1)
+    flair = 0.35 + 0.4 * x0 + 0.05 * rng.standard_normal(x0.shape)
+    flair = ((flair - flair.mean()) / flair.std()).astype(np.float32)          # UT:511 z-score
+    a, b = x0[..., 0] >= thr, y2[..., 0] >= thr
+    lab = np.zeros(a.shape, np.int64)
+    lab[a & ~b] = 1
+    lab[~a & b] = 2
+    lab[a & b] = 3
+    onehot = np.eye(4, dtype=np.float32)[lab]
+    return flair, z, onehot

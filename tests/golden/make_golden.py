@@ -58,7 +58,39 @@ def case(name, img, B, seed):
     print(name, "written")
 
 
+def uresnet_case(name, img, B, seed, drop_seed):
+    """DEP-UResNet: phase-0 predict, one phase-1 gradient evaluation (fp64 oracle) and two
+    train_on_batch steps of the fp32 oracle."""
+    import torch
+    P = uresnet_params(seed)
+    x, z, lab = O.synth_uresnet_batch(seed + 3, B, img, img)
+    out = dict(img=img, B=B, seed=seed, drop_seed=drop_seed, wsum=checks(P),
+               xsum=float(x.astype(np.float64).sum()), labsum=lab.reshape(-1, 4).sum(0))
+    probs = O.uresnet_predict(P, x, z)
+    rng = np.random.default_rng(321)
+    idx = rng.integers(0, probs.size, 256)
+    out["probs_idx"], out["probs_samples"] = idx, probs.reshape(-1)[idx]
+    out["eval_loss"] = float(O.keras_categorical_crossentropy_t(torch.tensor(probs), torch.tensor(lab)))
+    loss, grads, stats = O.uresnet_grads(P, x, z, lab, drop_seed=drop_seed, dtype=torch.float64)
+    out["loss"] = loss
+    out["gnorm"] = np.array([float(np.sqrt((np.asarray(g, np.float64) ** 2).sum())) for g in grads.values()])
+    out["keep_sum"] = int(O.dropout_keep_mask(drop_seed, (B, img // 4, img // 4, 96)).sum())
+    tr = O.OracleUResNet(P)
+    out["step_losses"] = np.array([tr.train_on_batch([x, z], lab, drop_seed=drop_seed + k) for k in range(2)])
+    out["post_wsum"] = checks(P)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "written")
+
+
+def uresnet_params(seed):
+    """Random-init DEP-UResNet weights with a head small enough that the softmax is not saturated."""
+    P = O.init_generator(seed, nc_out=4, randomize_bn=True, bias_std=0.05)
+    P["gen_segmentation/kernel"] = (P["gen_segmentation/kernel"] * 0.05).astype(np.float32)
+    return P
+
+
 if __name__ == "__main__":
     case("small_64_b2", 64, 2, 11)
+    uresnet_case("uresnet_64_b4", 64, 4, 41, 2024)
     if "--full" in sys.argv:
         case("full_256_b2", 256, 2, 21)

@@ -108,3 +108,71 @@ def test_param_counts_match_survey():
     PG = O.init_generator(0)
     assert sum(PG[n].size for n in O.trainable_names(PG)) == 2486145
     assert sum(v.size for v in O.init_critic(0).values()) == 1798002
+
+
+# ---------------------------------------------------------------------------
+# DEP-UResNet supervised path
+# ---------------------------------------------------------------------------
+def _uresnet_setup(g):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    img, B, seed = int(g["img"]), int(g["B"]), int(g["seed"])
+    P = mg.uresnet_params(seed)
+    x, z, lab = O.synth_uresnet_batch(seed + 3, B, img, img)
+    return P, x, z, lab
+
+
+def test_uresnet_oracle_matches_golden():
+    g = np.load(os.path.join(GOLD, "uresnet_64_b4.npz"))
+    P, x, z, lab = _uresnet_setup(g)
+    np.testing.assert_allclose(_checks(P), g["wsum"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(lab.reshape(-1, 4).sum(0), g["labsum"])
+    probs = O.uresnet_predict(P, x, z)
+    np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(probs.reshape(-1)[g["probs_idx"]], g["probs_samples"], rtol=2e-4, atol=2e-6)
+    ds = int(g["drop_seed"])
+    assert int(O.dropout_keep_mask(ds, (int(g["B"]), 16, 16, 96)).sum()) == int(g["keep_sum"])
+    loss, grads, stats = O.uresnet_grads(P, x, z, lab, drop_seed=ds)          # fp32 against the stored fp64
+    assert abs(loss - float(g["loss"])) < 1e-4
+    gn = np.array([float(np.sqrt((np.asarray(v, np.float64) ** 2).sum())) for v in grads.values()])
+    big = g["gnorm"] > 1e-6
+    np.testing.assert_allclose(gn[big], g["gnorm"][big], rtol=2e-2)
+    tr = O.OracleUResNet(P)
+    losses = [tr.train_on_batch([x, z], lab, drop_seed=ds + k) for k in range(2)]
+    np.testing.assert_allclose(losses, g["step_losses"], rtol=2e-3)
+    np.testing.assert_allclose(_checks(P), g["post_wsum"], rtol=1e-3, atol=5e-2)
+
+
+def test_uresnet_phase1_properties():
+    """What learning phase 1 changes: biases in front of a batch-statistics BN get a zero gradient, the moving
+    statistics move by (1 - 0.99) of the batch statistics with the keras variance corrections, dropout keeps
+    ~75 % and rescales by 4/3, and the loss is keras' clipped cross-entropy."""
+    P = O.init_generator(3, nc_out=4, randomize_bn=True, bias_std=0.05)
+    x, z, lab = O.synth_uresnet_batch(8, 3, 32, 32)
+    loss, grads, stats = O.uresnet_grads(P, x, z, lab, drop_seed=None, dtype=torch.float64)
+    scale = max(float(np.abs(v).max()) for v in grads.values())
+    for k, v in grads.items():
+        if k.endswith("/bias") and not k.startswith("gen_segmentation"):
+            assert float(np.abs(v).max()) < 1e-10 * scale, k
+    assert float(np.abs(grads["gen_segmentation/bias"]).max()) > 1e-6 * scale
+    name = "bn_gen_0"
+    mean, var, n, fused = stats[name]
+    assert fused and n == 3 * 32 * 32
+    mean1, var1, n1, fused1 = stats["dense_bn_noise_2_mul"]
+    assert not fused1 and n1 == 3
+    P0 = {k: v.copy() for k, v in P.items()}
+    O.OracleUResNet(P).train_on_batch([x, z], lab)
+    np.testing.assert_allclose(P[name + "/moving_mean"], 0.99 * P0[name + "/moving_mean"] + 0.01 * mean.numpy(),
+                               rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(P[name + "/moving_variance"],
+                               0.99 * P0[name + "/moving_variance"] + 0.01 * var.numpy() * n / (n - 1.0),
+                               rtol=1e-4, atol=1e-6)
+    keep = O.dropout_keep_mask(99, (4, 16, 16, 96))
+    assert abs(keep.mean() - 0.75) < 0.01
+    assert not np.array_equal(keep, O.dropout_keep_mask(100, (4, 16, 16, 96)))
+    p = torch.tensor([[0.25, 0.25, 0.25, 0.25], [1.0, 0.0, 0.0, 0.0]], dtype=torch.float64)
+    t = torch.tensor([[0.0, 1.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]], dtype=torch.float64)
+    want = 0.5 * (-np.log(0.25) - np.log(1e-7))
+    assert abs(float(O.keras_categorical_crossentropy_t(p, t)) - want) < 1e-9
