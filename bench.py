@@ -77,6 +77,20 @@ def cpu_baseline(sample_batch):
                       "torch-CPU restatement of the Keras graph (oracle/depgan_oracle.py), %.1f s" % (sample_batch, dt)}
 
 
+def pmc_traffic(batch):
+    """HBM bytes per launch of the igemm class from the committed PMC passes over this same command
+    (tools/pmc_traffic.py; counters cannot be read from inside the process being timed)."""
+    best = None
+    for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if f.endswith("pmc_traffic.json"):
+            best = f
+    if best is None or batch != 32:
+        return None, "no PMC pass for this configuration"
+    with open(os.path.join(ROOT, "profiles", best)) as fh:
+        d = json.load(fh)
+    return round(d["igemm_conv_kernel_class"]["hbm_bytes_per_launch"]), "profiles/" + best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,13 +159,18 @@ def main():
     for _ in range(2):
         step()
     conv_ms, conv_n, conv_fl = eng.profile_read(0)
+    conv_bytes = eng.profile_read_bytes(0)
     wg_ms, wg_n, wg_fl = eng.profile_read(1)
     ot_ms, ot_n, _ = eng.profile_read(2)
     eng.profile(False)
     eng.profile_reset()
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(B)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
+                "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; "
+                                "%s)" % traffic_src,
+                "algorithmic_bytes_per_launch": round(conv_bytes / max(conv_n, 1)),
                 "kernel": "igemm_conv_kernel (all shapes: fwd / bwd-data / GP u-forward)",
                 "avg_launch_us": round(conv_ms / max(conv_n, 1) * 1e3, 2), "launches_per_step": conv_n // 2,
                 "wgrad": {"achieved": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2) if wg_ms > 0 else 0.0,

@@ -17,7 +17,7 @@ EXPORTS = [
     "depgan_g_step", "depgan_apply_adam", "depgan_last_sums", "depgan_profile_enable", "depgan_profile_read",
     "depgan_profile_reset", "depgan_profile_dump", "depgan_op_conv2d", "depgan_op_conv2d_bwd_data", "depgan_op_conv2d_wgrad",
     "depgan_op_maxpool", "depgan_op_conv2d_stamps", "depgan_uresnet_grads", "depgan_uresnet_step",
-    "depgan_uresnet_eval",
+    "depgan_uresnet_eval", "depgan_profile_read_bytes", "depgan_g_eval_multi",
 ]
 
 
@@ -67,11 +67,13 @@ def load():
     lib.depgan_critic_step.argtypes = [vp, C.c_int, vp, vp, vp, vp, fp]
     lib.depgan_g_eval.argtypes = [vp, vp, vp, vp, fp]
     lib.depgan_g_grads.argtypes = [vp, vp, vp, vp, fp]
+    lib.depgan_g_eval_multi.argtypes = [vp, vp, vp, vp, C.c_int, fp, fp]
     lib.depgan_g_step.argtypes = [vp, vp, vp, vp, fp]
     lib.depgan_apply_adam.argtypes = [vp, C.c_int]
     lib.depgan_last_sums.argtypes = [vp, fp]
     lib.depgan_profile_enable.argtypes = [vp, C.c_int]
     lib.depgan_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]
+    lib.depgan_profile_read_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     lib.depgan_profile_reset.argtypes = [vp]
     lib.depgan_profile_dump.argtypes = [vp, C.c_char_p]
     lib.depgan_op_conv2d.argtypes = [vp, vp, vp, vp] + [C.c_int] * 8 + [vp]

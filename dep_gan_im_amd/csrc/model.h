@@ -91,6 +91,7 @@ struct ProfRec {
   hipEvent_t a, b;
   int klass;
   double flops;
+  double bytes;   // algorithmic HBM bytes of the launch (operands read once, results written once)
   char label[56];
 };
 
@@ -135,6 +136,7 @@ struct depgan_ctx {
   float* Sraw = nullptr;           // [256] raw column sums
   float* scratch = nullptr;        // reductions
   float* scal = nullptr;           // device scalars
+  float* scal_multi = nullptr;     // 8 floats per evaluation of depgan_g_eval_multi
   float* fake_y2 = nullptr;        // [B*H*W]
   float last_sums[8];
 
@@ -156,11 +158,13 @@ struct depgan_ctx {
 struct ProfScope {
   depgan_ctx* c;
   bool live;
-  ProfScope(depgan_ctx* c_, int klass, double flops, const char* label = "") : c(c_), live(c_->prof_on) {
+  ProfScope(depgan_ctx* c_, int klass, double flops, const char* label = "", double bytes = 0.0)
+      : c(c_), live(c_->prof_on) {
     if (!live) return;
     ProfRec r;
     r.klass = klass;
     r.flops = flops;
+    r.bytes = bytes;
     strncpy(r.label, label, sizeof(r.label) - 1);
     r.label[sizeof(r.label) - 1] = 0;
     hipEventCreate(&r.a);

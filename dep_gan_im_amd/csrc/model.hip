@@ -80,8 +80,13 @@ int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
   const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cin * a.Cout * KS * KS;
   char lb[56];
   snprintf(lb, sizeof(lb), "conv k%d b%d %dx%d %d->%d", KS, a.B, a.H, a.W, a.Cin, a.Cout);
+  // algorithmic bytes: every operand the epilogue names read once, every result written once, weights once
+  const double px = 4.0 * a.B * a.H * a.W;
+  const double by = px * a.Cin + px * a.Cout * (1 + (a.ep.res.p ? 1 : 0) + (a.ep.mask.p ? 1 : 0) +
+                                                (a.ep.out_pre.p ? 1 : 0) + (a.ep.accumulate ? 1 : 0)) +
+                    4.0 * KS * KS * a.Cin * a.Cout;
   if (pl.variant >= 0) {
-    ProfScope ps(c, 0, fl, lb);
+    ProfScope ps(c, 0, fl, lb, by);
     return dg_conv_igemm(pl, a, c->st);
   }
   ProfScope ps(c, 2, fl, lb);
@@ -854,8 +859,10 @@ static int critic_grads(depgan_ctx* c, int which, const float* y2, const float* 
   return DG_OK;
 }
 
-static int g_eval_impl(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6], bool train) {
-  if (c->cfg.nc_out != 1) { dg_set_error("the WGAN-GP closures need nc_out == 1"); return DG_ERR_ARG; }
+// device part of one generator-loss evaluation; leaves [mean D_y2(fake), mean D_dem(attr), -, -, sum|attr-real_dem|,
+// sum wr, sum wf, sum wr*wf] in scal_dev[0..8)
+static int g_eval_enqueue(depgan_ctx* c, const float* x, const float* y2, const float* z, bool train,
+                          float* scal_dev) {
   const int B = c->cfg.batch, H0 = c->cfg.height, W0 = c->cfg.width;
   const long HW0 = (long)H0 * W0, P = (long)B * HW0;
   DGCHECK(g_forward(c, x, z, B, train));
@@ -867,8 +874,8 @@ static int g_eval_impl(depgan_ctx* c, const float* x, const float* y2, const flo
   DGCHECK(d_forward(c, c->d[1], c->attr.p, B, B));
   {
     ProfScope ps(c, 2, 0.0);
-    DGCHECK(dg_mean_groups(c->d_out, c->scal, 2, B, c->st));
-    DGCHECK(dg_gloss_sums(x, c->cfg.nicg, y2, c->attr.p, c->cfg.im_thresh, c->scal + 4, P, c->scratch, c->st));
+    DGCHECK(dg_mean_groups(c->d_out, scal_dev, 2, B, c->st));
+    DGCHECK(dg_gloss_sums(x, c->cfg.nicg, y2, c->attr.p, c->cfg.im_thresh, scal_dev + 4, P, c->scratch, c->st));
   }
   if (train) {
     // d loss / d attr needs dD/dimage of both critics with upstream 1 per sample (GT:592)
@@ -880,9 +887,13 @@ static int g_eval_impl(depgan_ctx* c, const float* x, const float* y2, const flo
     }
     DGCHECK(g_backward(c, x, z, B));
   }
-  float h[8];
-  HIPCHECK(hipMemcpyAsync(h, c->scal, 8 * sizeof(float), hipMemcpyDeviceToHost, c->st));
-  HIPCHECK(hipStreamSynchronize(c->st));
+  return DG_OK;
+}
+
+// host part: the six reported scalars and the un-normalised pieces from the 8 device values
+static void g_eval_finish(const depgan_ctx* c, const float h[8], float out[6], float sums[8]) {
+  const int B = c->cfg.batch;
+  const long P = (long)B * c->cfg.height * c->cfg.width;
   const double lf = h[0], lfd = h[1], sabs = h[4], swr = h[5], swf = h[6], sin_ = h[7];
   const double m1 = 100.0 * sabs / (double)P;                        // GT:576
   const double dv = swr / 1000.0 - swf / 1000.0;
@@ -895,14 +906,23 @@ static int g_eval_impl(depgan_ctx* c, const float* x, const float* y2, const flo
   out[3] = (float)m1;
   out[4] = (float)m3;
   out[5] = (float)m4;
-  c->last_sums[0] = (float)(lf * B);
-  c->last_sums[1] = (float)(lfd * B);
-  c->last_sums[2] = (float)sabs;
-  c->last_sums[3] = (float)swr;
-  c->last_sums[4] = (float)swf;
-  c->last_sums[5] = (float)sin_;
-  c->last_sums[6] = (float)B;
-  c->last_sums[7] = (float)P;
+  sums[0] = (float)(lf * B);
+  sums[1] = (float)(lfd * B);
+  sums[2] = (float)sabs;
+  sums[3] = (float)swr;
+  sums[4] = (float)swf;
+  sums[5] = (float)sin_;
+  sums[6] = (float)B;
+  sums[7] = (float)P;
+}
+
+static int g_eval_impl(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6], bool train) {
+  if (c->cfg.nc_out != 1) { dg_set_error("the WGAN-GP closures need nc_out == 1"); return DG_ERR_ARG; }
+  DGCHECK(g_eval_enqueue(c, x, y2, z, train, c->scal));
+  float h[8];
+  HIPCHECK(hipMemcpyAsync(h, c->scal, 8 * sizeof(float), hipMemcpyDeviceToHost, c->st));
+  HIPCHECK(hipStreamSynchronize(c->st));
+  g_eval_finish(c, h, out, c->last_sums);
   return DG_OK;
 }
 
@@ -968,6 +988,7 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
   if (rc == DG_OK) rc = dmalloc(c, &c->Sraw, 256);
   if (rc == DG_OK) rc = dmalloc(c, &c->scratch, (size_t)(1 << 20) + (size_t)cfg->batch * 20000);
   if (rc == DG_OK) rc = dmalloc(c, &c->scal, 16);
+  if (rc == DG_OK) rc = dmalloc(c, &c->scal_multi, 8 * DEPGAN_MAX_MULTI);
   if (rc != DG_OK) {
     depgan_destroy(c);
     return rc;
@@ -1079,6 +1100,19 @@ int depgan_critic_step(depgan_ctx* c, int net, const float* y2, const float* x, 
 int depgan_g_eval(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6]) {
   return g_eval_impl(c, x, y2, z, out, false);
 }
+int depgan_g_eval_multi(depgan_ctx* c, const float* x, const float* y2, const float* z_all, int k, float* out,
+                        float* sums) {
+  if (c->cfg.nc_out != 1) { dg_set_error("the WGAN-GP closures need nc_out == 1"); return DG_ERR_ARG; }
+  if (k < 1 || k > DEPGAN_MAX_MULTI) { dg_set_error("g_eval_multi: k must be in [1, %d]", DEPGAN_MAX_MULTI); return DG_ERR_ARG; }
+  const size_t zstride = (size_t)c->cfg.batch * 32;
+  for (int i = 0; i < k; ++i) DGCHECK(g_eval_enqueue(c, x, y2, z_all + i * zstride, false, c->scal_multi + 8 * i));
+  float h[8 * DEPGAN_MAX_MULTI];
+  HIPCHECK(hipMemcpyAsync(h, c->scal_multi, (size_t)8 * k * sizeof(float), hipMemcpyDeviceToHost, c->st));
+  HIPCHECK(hipStreamSynchronize(c->st));      // the only host synchronisation of the k evaluations
+  float tmp[8];
+  for (int i = 0; i < k; ++i) g_eval_finish(c, h + 8 * i, out + 6 * i, sums ? sums + 8 * i : tmp);
+  return DG_OK;
+}
 int depgan_g_grads(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6]) {
   return g_eval_impl(c, x, y2, z, out, true);
 }
@@ -1120,6 +1154,14 @@ int depgan_profile_read(depgan_ctx* c, int klass, double* total_ms, long* launch
   *total_ms = ms;
   *launches = n;
   *flops = fl;
+  return DG_OK;
+}
+
+int depgan_profile_read_bytes(depgan_ctx* c, int klass, double* bytes) {
+  double by = 0;
+  for (ProfRec& r : c->recs)
+    if (r.klass == klass) by += r.bytes;
+  *bytes = by;
   return DG_OK;
 }
 

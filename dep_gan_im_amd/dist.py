@@ -75,6 +75,14 @@ class DataParallel:
         self._allreduce_grads(engine, which)
         return combine_critic_sums(self._allreduce_sums(engine, 4))
 
+    def reduce_generator_many(self, sums, device=None):
+        """k x 8 un-normalised pieces -> k x 6 global scalars with ONE all-reduce (same choice on every rank)."""
+        s = torch.tensor(sums, dtype=torch.float64)
+        if device is not None and dist.get_backend(self.group) == "nccl":
+            s = s.to(device)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+        return [combine_generator_sums(row) for row in s.cpu().tolist()]
+
     def reduce_generator(self, engine, out, grads):
         if grads:
             self._allreduce_grads(engine, "G")

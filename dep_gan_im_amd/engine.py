@@ -215,6 +215,28 @@ class Engine:
         check(fn(self.h, self._p(x), self._p(y2), self._p(z), out), "generator " + mode)
         return [float(v) for v in out]
 
+    def generator_eval_multi(self, x, y2, zs):
+        """k forward-only loss evaluations on one batch with k noises (GT:868-877), one host sync.
+        zs: (k, B, 32, 1) array / tensor or a list of k (B,32,1) noises.  Returns (k x 6 outputs, k x 8 sums)."""
+        torch = _torch()
+        B = self.batch
+        x = self._dev(x, (B, self.height, self.width, self.nicg))
+        y2 = self._dev(y2, (B, self.height, self.width, 1))
+        if isinstance(zs, (list, tuple)):
+            zs = torch.stack([self._dev(z).reshape(B, 32) for z in zs])
+        else:
+            zs = self._dev(zs)
+        k = int(zs.shape[0])
+        zs = zs.reshape(k, -1).contiguous()
+        if zs.shape[1] != B * 32:
+            raise ValueError("noises must be (k,%d,32,1)" % B)
+        out, sums = (C.c_float * (6 * k))(), (C.c_float * (8 * k))()
+        self._use_current_stream()
+        check(self.lib.depgan_g_eval_multi(self.h, self._p(x), self._p(y2), self._p(zs), k, out, sums),
+              "depgan_g_eval_multi")
+        return ([[float(out[6 * i + j]) for j in range(6)] for i in range(k)],
+                [[float(sums[8 * i + j]) for j in range(8)] for i in range(k)])
+
     # ---- DEP-UResNet supervised path (nc_out = 4) ----
     def uresnet(self, x, z, labels, mode="step", drop_seed=0):
         """mode 'step' = train_on_batch (UT:602-606), 'grads' = gradients only, 'eval' = phase-0 loss.
@@ -262,3 +284,8 @@ class Engine:
         ms, n, fl = C.c_double(), C.c_long(), C.c_double()
         check(self.lib.depgan_profile_read(self.h, klass, C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
+
+    def profile_read_bytes(self, klass):
+        by = C.c_double()
+        check(self.lib.depgan_profile_read_bytes(self.h, klass, C.byref(by)))
+        return by.value

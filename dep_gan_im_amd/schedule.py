@@ -74,10 +74,13 @@ def train_epoch(trainers, data_1tp, data_2tp, batchSize=16, Diters=5, k_noise=10
             state.crit_dem_iterations += 1
         # generator: best of k_noise on the batch the DEM loop used last (GT:868-878)
         noises = rng.normal(size=(k_noise, batchSize, noiseSize, 1)).astype("float32")
-        losses_errG = []
-        for k in range(k_noise):
-            out = trainers.netG_no_update([real_data_1tp, real_data_2tp, noises[k]])
-            losses_errG.append(out[0])
+        if hasattr(trainers, "netG_no_update_many"):                # one enqueue, one host sync for the k calls
+            losses_errG = [o[0] for o in trainers.netG_no_update_many([real_data_1tp, real_data_2tp, noises])]
+        else:
+            losses_errG = []
+            for k in range(k_noise):
+                out = trainers.netG_no_update([real_data_1tp, real_data_2tp, noises[k]])
+                losses_errG.append(out[0])
         best = int(np.array(losses_errG).argmin(0))
         errG, errG_CY2, errG_DEM, errG_MSE, errG_VOL, errG_WMH = trainers.netG_train(
             [real_data_1tp, real_data_2tp, noises[best]])

@@ -49,6 +49,17 @@ class Trainers:
             out = self.dist.reduce_generator(self.engine, out, grads=False)
         return out
 
+    def netG_no_update_many(self, inputs):
+        """[x, y2, [z_0 .. z_{k-1}]] -> k lists of the six netG_no_update scalars: the driver's best-of-k noise
+        search (GT:868-877) as one enqueue with one host synchronisation instead of k closure calls."""
+        if not isinstance(inputs, (list, tuple)) or len(inputs) != 3:
+            raise ValueError("generator closure expects [real_1tp, real_2tp, noises]")
+        x, y2, zs = inputs
+        outs, sums = self.engine.generator_eval_multi(x, y2, zs)
+        if self.dist is not None:
+            outs = self.dist.reduce_generator_many(sums, getattr(self.engine, "device", None))
+        return outs
+
     def netG_train(self, inputs):
         if not isinstance(inputs, (list, tuple)) or len(inputs) != 3:
             raise ValueError("generator closure expects [real_1tp, real_2tp, noise]")

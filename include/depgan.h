@@ -71,6 +71,13 @@ int depgan_critic_step(depgan_ctx* ctx, int net, const float* y2_dev, const floa
 /* netG_no_update / netG_train ([x, y2, z] -> [loss, loss_fake, loss_fake_dem, M1, M3, M4]; GT:595-598) */
 int depgan_g_eval(depgan_ctx* ctx, const float* x_dev, const float* y2_dev, const float* z_dev, float out_host[6]);
 int depgan_g_grads(depgan_ctx* ctx, const float* x_dev, const float* y2_dev, const float* z_dev, float out_host[6]);
+/* The best-of-k noise search of the driver (GT:868-877: k = 10 calls of netG_no_update on the SAME batch with k
+ * noises, then argmin of the total loss): k evaluations enqueued back to back, one host synchronisation.
+ * z_all_dev: (k, batch, 32) ; out_host: k x 6 scalars as depgan_g_eval ; sums_host (may be NULL): k x 8
+ * un-normalised pieces as depgan_last_sums (for the data-parallel combine).  1 <= k <= DEPGAN_MAX_MULTI. */
+#define DEPGAN_MAX_MULTI 32
+int depgan_g_eval_multi(depgan_ctx* ctx, const float* x_dev, const float* y2_dev, const float* z_all_dev, int k,
+                        float* out_host, float* sums_host);
 int depgan_g_step(depgan_ctx* ctx, const float* x_dev, const float* y2_dev, const float* z_dev, float out_host[6]);
 int depgan_apply_adam(depgan_ctx* ctx, int net);
 
@@ -98,6 +105,8 @@ int depgan_last_sums(depgan_ctx* ctx, float out_host[8]);
 int depgan_profile_enable(depgan_ctx* ctx, int on);
 /* class 0: MFMA conv (fwd / bwd-data / u-forward), 1: MFMA wgrad, 2: everything else */
 int depgan_profile_read(depgan_ctx* ctx, int klass, double* total_ms, long* launches, double* flops);
+/* sum over the class's recorded launches of the algorithmic HBM bytes (operands once, results once; class 0 only) */
+int depgan_profile_read_bytes(depgan_ctx* ctx, int klass, double* bytes);
 int depgan_profile_reset(depgan_ctx* ctx);
 /* one CSV row per recorded launch: class,label,ms,gflop */
 int depgan_profile_dump(depgan_ctx* ctx, const char* path);

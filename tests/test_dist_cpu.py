@@ -41,7 +41,8 @@ def _worker(rank, world, port, q):
     out_g = dp.reduce_generator(eng, None, grads=True)
     eng2 = FakeEngine(g, _sums_for(rank)[:2] + [1.5, 4.0])
     out_c = dp.reduce_critic(eng2, "D_y2", None)
-    q.put((rank, out_g, eng.grad_tensor("G").tolist(), out_c, eng2.grad_tensor("D_y2").tolist()))
+    many = dp.reduce_generator_many([_sums_for(10 * k + rank) for k in range(3)])
+    q.put((rank, out_g, eng.grad_tensor("G").tolist(), out_c, eng2.grad_tensor("D_y2").tolist(), many))
     dist.destroy_process_group()
 
 
@@ -61,7 +62,10 @@ def test_two_rank_reduction_matches_single_process():
         assert p.exitcode == 0
     tot = [a + b for a, b in zip(_sums_for(0), _sums_for(1))]
     want_g = combine_generator_sums(tot)
-    for rank, out_g, gG, out_c, gD in res:
+    want_many = [combine_generator_sums([a + b for a, b in zip(_sums_for(10 * k), _sums_for(10 * k + 1))])
+                 for k in range(3)]
+    for rank, out_g, gG, out_c, gD, many in res:
+        np.testing.assert_allclose(many, want_many, rtol=1e-12)     # best-of-k: one all-reduce, same on all ranks
         np.testing.assert_allclose(out_g, want_g, rtol=1e-12)
         np.testing.assert_allclose(gG, np.full(10, 1.5), rtol=1e-6)          # mean of 1 and 2
         np.testing.assert_allclose(gD, np.arange(6.0) * 1.5, rtol=1e-6)

@@ -295,3 +295,25 @@ def test_reference_schedule_one_generator_iteration(lib):
     if gap[1] - gap[0] > 6e-3 * abs(gap[0]):
         assert a["best_noise"] == b["best_noise"]
     assert abs(a["errG"] - b["errG"]) < 3e-3 * abs(b["errG"])
+
+
+def test_best_of_k_multi_eval_equals_k_single_evals(lib):
+    """depgan_g_eval_multi (one enqueue, one host sync; GT:868-877) returns exactly what k calls of netG_no_update
+    return, and leaves no state behind that changes a following training step."""
+    PG, PD1, PD2, x, y2, z, ep = _setup(64, 2, 91)
+    eng = _engine(64, 2, PG, PD1, PD2)
+    zs = np.random.default_rng(4).normal(size=(5, 2, 32, 1)).astype(np.float32)
+    single = [eng.generator(x, y2, zs[k], "eval") for k in range(5)]
+    sums1 = []
+    for k in range(5):
+        eng.generator(x, y2, zs[k], "eval")
+        sums1.append(eng.last_sums())
+    outs, sums = eng.generator_eval_multi(x, y2, zs)
+    assert outs == single and sums == sums1
+    outs2, _ = eng.generator_eval_multi(x, y2, [zs[k] for k in range(5)])      # list-of-noises form
+    assert outs2 == single
+    with pytest.raises(Exception):
+        eng.generator_eval_multi(x, y2, np.zeros((33, 2, 32, 1), np.float32))
+    from dep_gan_im_amd.trainers import Trainers
+    assert Trainers(eng).netG_no_update_many([x, y2, zs]) == single
+    eng.close()
