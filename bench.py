@@ -165,6 +165,16 @@ def main():
     eng.profile(False)
     eng.profile_reset()
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # north_star's secondary target: generator forward alone (A1/A12, 23.513 GFLOP/slice) at this batch
+    torch.cuda.synchronize()
+    out = eng.g_forward(x, z)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        out = eng.g_forward(x, z)
+    torch.cuda.synchronize()
+    gf_ms = (time.perf_counter() - t1) / 5 * 1e3
+    gf_tf = 23.513e9 * B / (gf_ms * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic(B)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": traffic,
@@ -177,7 +187,9 @@ def main():
                           "ms_per_step": round(wg_ms / 2, 3)},
                 "ms_per_step": {"igemm_conv": round(conv_ms / 2, 3), "wgrad": round(wg_ms / 2, 3),
                                 "other": round(ot_ms / 2, 3)},
-                "whole_step_frac": round(GFLOP_PER_SLICE * 1e9 * B / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA, 4)}
+                "whole_step_frac": round(GFLOP_PER_SLICE * 1e9 * B / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA, 4),
+                "g_forward": {"ms": round(gf_ms, 3), "achieved": round(gf_tf, 2),
+                              "frac": round(gf_tf / PEAK_F32_MFMA, 4), "slices_per_s": round(B / (gf_ms * 1e-3), 1)}}
 
     if rank == 0:
         line = {"metric": "2D slices/sec (G+2D+GP train step), 256x256x1 fp32", "value": round(value, 3),

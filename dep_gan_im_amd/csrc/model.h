@@ -184,8 +184,14 @@ int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS);
 void zero_ep(Epilogue* e);
 TView view_offset(TView v, long samples);
 TView strided2(TView v, int di, int dj);
+// column sums of dy over its first B samples, delivered with the weight gradient: out = scale * sum, raw = sum
+struct ColSum {
+  int B;
+  const float* scale;
+  float *out, *raw;
+};
 int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, int Cin, int Cout, const float* scale,
-               float* out, float* raw, int accumulate, int oi);
+               float* out, float* raw, int accumulate, int oi, const ColSum* cs = nullptr);
 int net_adam(depgan_ctx* c, Net& n);
 int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u);
 int refresh_generator(depgan_ctx* c);

@@ -112,7 +112,7 @@ TView strided2(TView v, int di, int dj) {  // pixel grid (2i+di, 2j+dj)
 
 // weight gradient: slabs + reduction (+ optional BN scale / raw copy / OI layout)
 int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, int Cin, int Cout,
-                      const float* scale, float* out, float* raw, int accumulate, int oi) {
+               const float* scale, float* out, float* raw, int accumulate, int oi, const ColSum* cs) {
   WgradArgs a;
   a.x = x;
   a.dy = dy;
@@ -127,6 +127,13 @@ int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, in
   const double fl = 2.0 * N * H * W * (double)Cin * Cout * KS * KS;
   char lb[56];
   snprintf(lb, sizeof(lb), "wgrad k%d b%d %dx%d %d->%d", KS, N, H, W, Cin, Cout);
+  if (cs) {
+    // Column sums of dy (bias / BN-beta gradients).  Riding them in the MFMA weight-gradient kernel was tried and
+    // dropped: its 3x3 variant holds 9 accumulator tiles and sits at the 256-VGPR limit of 2 workgroups per CU,
+    // the 4 extra live registers cost 10 % of its rate -- more than this separate streaming pass.
+    ProfScope ps(c, 2, 0.0, "colsum");
+    DGCHECK(dg_colsum(dy, cs->B, H, W, Cout, cs->scale, cs->out, cs->raw, 0, c->scratch, c->st));
+  }
   if (Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 8) {
     if (dg_wgrad_part_floats(KS, N, H, W, Cin, Cout) > c->partFloats) {
       dg_set_error("wgrad slab workspace too small");
@@ -142,7 +149,7 @@ int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, in
     ProfScope ps(c, 2, fl, lb);
     DGCHECK(dg_wgrad_small(KS, a, &nch, c->st));
   }
-  ProfScope ps(c, 2, 0.0);
+  ProfScope ps(c, 2, 0.0, "slab reduce");
   return dg_wgrad_reduce(c->part, nch, KS * KS, Cin, Cout, scale, out, raw, accumulate, oi, c->st);
 }
 
@@ -591,15 +598,12 @@ int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u
 // conv + phase-0 BN backward given dy (grad at the BN output); see _conv_bn_bwd in oracle/manual.py
 static int g_conv_bn_bwd(depgan_ctx* c, GLayer& L, size_t li, const float* x_user, TView dy, TView res, int n) {
   TView xin = (li == 0) ? make_view(const_cast<float*>(x_user), L.H, L.W, L.Cin) : L.in;
+  // db = s * sum dy, dbeta = sum dy: column sums fused into the weight-gradient launch
+  const ColSum cs = {n, L.s, L.db, L.dbeta};
+  DGCHECK(wgrad_full(c, 3, xin, dy, n, L.H, L.W, L.Cin, L.Cout, L.s, L.dW, c->raw, 0, 0, &cs));
   {
     ProfScope ps(c, 2, 0.0);
-    DGCHECK(dg_colsum(dy, n, L.H, L.W, L.Cout, L.s, L.db, c->Sraw, 0, c->scratch, c->st));
-    HIPCHECK(hipMemcpyAsync(L.dbeta, c->Sraw, L.Cout * sizeof(float), hipMemcpyDeviceToDevice, c->st));
-  }
-  DGCHECK(wgrad_full(c, 3, xin, dy, n, L.H, L.W, L.Cin, L.Cout, L.s, L.dW, c->raw, 0, 0));
-  {
-    ProfScope ps(c, 2, 0.0);
-    DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 9 * L.Cin, L.Cout, 0, L.Cin, L.b, L.mean, L.rstd, c->Sraw, L.dgamma,
+    DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 9 * L.Cin, L.Cout, 0, L.Cin, L.b, L.mean, L.rstd, L.dbeta, L.dgamma,
                              c->st));
   }
   if (li == 0) return DG_OK;
@@ -644,8 +648,7 @@ int g_backward(depgan_ctx* c, const float* x, const float* z, int n) {
       const int Ho = 2 * L.H, Wo = 2 * L.W;
       {
         ProfScope ps(c, 2, 0.0);
-        DGCHECK(dg_colsum(L.dout, n, Ho, Wo, L.Cout, L.s, L.db, c->Sraw, 0, c->scratch, c->st));
-        HIPCHECK(hipMemcpyAsync(L.dbeta, c->Sraw, L.Cout * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+        DGCHECK(dg_colsum(L.dout, n, Ho, Wo, L.Cout, L.s, L.db, L.dbeta, 0, c->scratch, c->st));
       }
       for (int t = 0; t < 4; ++t) {
         const size_t o = (size_t)t * L.Cout * L.Cin;
@@ -654,7 +657,7 @@ int g_backward(depgan_ctx* c, const float* x, const float* z, int n) {
       }
       {
         ProfScope ps(c, 2, 0.0);
-        DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 4 * L.Cin, L.Cout, 1, L.Cin, L.b, L.mean, L.rstd, c->Sraw, L.dgamma,
+        DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 4 * L.Cin, L.Cout, 1, L.Cin, L.b, L.mean, L.rstd, L.dbeta, L.dgamma,
                                  c->st));
       }
       for (int t = 0; t < 4; ++t) {
@@ -827,23 +830,19 @@ static int critic_grads(depgan_ctx* c, int which, const float* y2, const float* 
   for (int l = 0; l < 11; ++l) {
     const DLayer& L = c->dl[l];
     TView xin = (l == 0) ? make_view(c->d_in, H0, W0, 1) : d_in_view(c, l, 0);
+    // bias gradient = column sums over the real and fake samples only (the penalty has no bias gradient, A6)
+    const ColSum cs = {2 * B, nullptr, D.db[l], nullptr};
     DGCHECK(wgrad_full(c, L.KS, xin, c->d_dz[l].view(), 3 * B, L.H, L.W, L.Cin, L.Cout, nullptr, D.dW[l], nullptr, 0,
-                       0));
-    ProfScope ps(c, 2, 0.0);
-    DGCHECK(dg_colsum(c->d_dz[l].view(), 2 * B, L.H, L.W, L.Cout, nullptr, D.db[l], nullptr, 0, c->scratch, c->st));
+                       0, &cs));
   }
   {
     ProfScope ps(c, 2, 0.0);
     const DLayer& T = c->dl[10];
     const int HW = T.H * T.W;
-    HIPCHECK(hipMemsetAsync(D.dw9, 0, 256 * sizeof(float), c->st));
-    HIPCHECK(hipMemsetAsync(D.db9, 0, sizeof(float), c->st));
-    HIPCHECK(hipMemsetAsync(D.dwd, 0, HW * sizeof(float), c->st));
-    HIPCHECK(hipMemsetAsync(D.dbd, 0, sizeof(float), c->st));
-    DGCHECK(dg_critic_tail_wgrad(c->d_act[10].p, D.w9, D.b9, D.wd, c->coefs, B, 1, D.dw9, D.db9, D.dwd, D.dbd,
+    DGCHECK(dg_critic_tail_wgrad(c->d_act[10].p, D.w9, D.b9, D.wd, c->coefs, B, 1, 0, D.dw9, D.db9, D.dwd, D.dbd,
                                  c->scratch, 2 * B, HW, 256, c->st));
     DGCHECK(dg_critic_tail_wgrad(c->d_act[10].p + (size_t)2 * B * c->d_act[10].per_sample(), D.w9, D.b9, D.wd,
-                                 c->coefs + 2, B, 0, D.dw9, D.db9, D.dwd, D.dbd, c->scratch, B, HW, 256, c->st));
+                                 c->coefs + 2, B, 0, 1, D.dw9, D.db9, D.dwd, D.dbd, c->scratch, B, HW, 256, c->st));
     DGCHECK(dg_mean_groups(c->d_out, c->scal, 2, B, c->st));
   }
   float h[3];

@@ -31,12 +31,13 @@ int dg_critic_tail_fwd(const float* a, const float* w9, const float* b9, const f
 int dg_critic_tail_bwd(const float* a, const float* w9, const float* wd, const float* coefs, int per, float* dz, int N,
                        int HW, int C, hipStream_t st);
 // tail weight gradients from T[n][p][c] = coef(n) * src[n][p][c]:
-//   dw9[c] += sum_{n,p} T wd[p] ; dwd[p] += sum_{n,c} T w9[c] (+ b9 * sum coef if add_bias_terms)
-//   db9 += sum_n coef(n) * sum_p wd[p] ; dbd += sum_n coef(n)      (only if add_bias_terms)
+//   dw9[c] (+)= sum_{n,p} T wd[p] ; dwd[p] (+)= sum_{n,c} T w9[c] (+ b9 * sum coef if add_bias_terms)
+//   db9 (+)= sum_n coef(n) * sum_p wd[p] ; dbd (+)= sum_n coef(n)      (only if add_bias_terms)
+// accumulate = 0 overwrites the outputs, 1 adds to them
 // scratch: N*(C+HW) floats
 int dg_critic_tail_wgrad(const float* src, const float* w9, const float* b9, const float* wd, const float* coefs,
-                         int per, int add_bias_terms, float* dw9, float* db9, float* dwd, float* dbd, float* scratch,
-                         int N, int HW, int C, hipStream_t st);
+                         int per, int add_bias_terms, int accumulate, float* dw9, float* db9, float* dwd, float* dbd,
+                         float* scratch, int N, int HW, int C, hipStream_t st);
 
 // column sums of an NHWC view: out[c] (+)= scale[c] * sum_{b,y,x} v[b,y,x,c]; raw (optional) gets the bare sum.
 // scratch: 1024*C floats

@@ -311,7 +311,7 @@ __global__ void critic_tail_wgrad_partial(const float* __restrict__ src, const f
 }
 __global__ void critic_tail_wgrad_final(const float* __restrict__ pw9, const float* __restrict__ pwd,
                                         const float* __restrict__ coefs, int per, int add_bias_terms,
-                                        const float* __restrict__ b9, const float* __restrict__ wd,
+                                        int accumulate, const float* __restrict__ b9, const float* __restrict__ wd,
                                         float* __restrict__ dw9, float* __restrict__ db9, float* __restrict__ dwd,
                                         float* __restrict__ dbd, int N, int HW, int C) {
   __shared__ float sh4[4];
@@ -320,34 +320,34 @@ __global__ void critic_tail_wgrad_final(const float* __restrict__ pw9, const flo
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
     for (int n = 0; n < N; ++n) s += coefs[n / per] * pw9[(size_t)n * C + c];
-    dw9[c] += s;
+    dw9[c] = accumulate ? dw9[c] + s : s;
   }
   float wsum = 0.f;
   for (int p = threadIdx.x; p < HW; p += blockDim.x) {
     float s = 0.f;
     for (int n = 0; n < N; ++n) s += coefs[n / per] * pwd[(size_t)n * HW + p];
     if (add_bias_terms) s += b9[0] * csum;
-    dwd[p] += s;
+    dwd[p] = accumulate ? dwd[p] + s : s;
     wsum += wd[p];
   }
   if (add_bias_terms) {
     wsum = block_sum(wsum, sh4);
     if (threadIdx.x == 0) {
-      db9[0] += csum * wsum;
-      dbd[0] += csum;
+      db9[0] = accumulate ? db9[0] + csum * wsum : csum * wsum;
+      dbd[0] = accumulate ? dbd[0] + csum : csum;
     }
   }
 }
 int dg_critic_tail_wgrad(const float* src, const float* w9, const float* b9, const float* wd, const float* coefs,
-                         int per, int add_bias_terms, float* dw9, float* db9, float* dwd, float* dbd, float* scratch,
+                         int per, int add_bias_terms, int accumulate, float* dw9, float* db9, float* dwd, float* dbd, float* scratch,
                          int N, int HW, int C, hipStream_t st) {
   if ((C % 4) || C > 256) { dg_set_error("dg_critic_tail_wgrad: C must be a multiple of 4 and <= 256"); return DG_ERR_ARG; }
   float* pw9 = scratch;
   float* pwd = scratch + (size_t)N * C;
   hipLaunchKernelGGL(critic_tail_wgrad_partial, dim3(N), dim3(256), 0, st, src, w9, wd, pw9, pwd, HW, C);
   HIPCHECK(hipGetLastError());
-  hipLaunchKernelGGL(critic_tail_wgrad_final, dim3(1), dim3(256), 0, st, pw9, pwd, coefs, per, add_bias_terms, b9,
-                     wd, dw9, db9, dwd, dbd, N, HW, C);
+  hipLaunchKernelGGL(critic_tail_wgrad_final, dim3(1), dim3(256), 0, st, pw9, pwd, coefs, per, add_bias_terms,
+                     accumulate, b9, wd, dw9, db9, dwd, dbd, N, HW, C);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
@@ -355,6 +355,9 @@ int dg_critic_tail_wgrad(const float* src, const float* w9, const float* b9, con
 // ---------------------------------------------------------------------------
 // column sums of an NHWC view
 // ---------------------------------------------------------------------------
+// FLAT: the view is pixel-contiguous (sY == W*sX, sB == H*sY: plain tensors and channel slices of the concat
+// buffers), so pixel q sits at q*sX and the loop carries no divisions; 4 independent loads in flight per thread.
+template <bool FLAT>
 __global__ void colsum_partial(TView v, long npix, int H, int W, int C4, float* __restrict__ part, int pixPerBlock,
                                const float* __restrict__ rowmul) {
   extern __shared__ __attribute__((aligned(16))) float sh[];  // [256][4]
@@ -365,15 +368,44 @@ __global__ void colsum_partial(TView v, long npix, int H, int W, int C4, float* 
   const long q1 = min(q0 + pixPerBlock, npix);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (pp < PP) {
-    for (long q = q0 + pp; q < q1; q += PP) {
-      const int x = (int)(q % W);
-      const long r = q / W;
-      const int y = (int)(r % H);
-      const int b = (int)(r / H);
-      const f32x4 a = *reinterpret_cast<const f32x4*>(v.p + view_off(v, b, y, x) + lp * 4);
-      const float m = rowmul ? rowmul[q] : 1.0f;
+    if (FLAT) {
+      f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, a3 = {0.f, 0.f, 0.f, 0.f};
+      const float* base = v.p + lp * 4;
+      long q = q0 + pp;
+      for (; q + 3 * PP < q1; q += 4 * PP) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(base + q * v.sX);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(base + (q + PP) * v.sX);
+        const f32x4 x2 = *reinterpret_cast<const f32x4*>(base + (q + 2 * PP) * v.sX);
+        const f32x4 x3 = *reinterpret_cast<const f32x4*>(base + (q + 3 * PP) * v.sX);
+        const float m0 = rowmul ? rowmul[q] : 1.0f, m1 = rowmul ? rowmul[q + PP] : 1.0f;
+        const float m2 = rowmul ? rowmul[q + 2 * PP] : 1.0f, m3 = rowmul ? rowmul[q + 3 * PP] : 1.0f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = fmaf(a[k], m, acc[k]);
+        for (int k = 0; k < 4; ++k) {
+          acc[k] = fmaf(x0[k], m0, acc[k]);
+          a1[k] = fmaf(x1[k], m1, a1[k]);
+          a2[k] = fmaf(x2[k], m2, a2[k]);
+          a3[k] = fmaf(x3[k], m3, a3[k]);
+        }
+      }
+      for (; q < q1; q += PP) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(base + q * v.sX);
+        const float m0 = rowmul ? rowmul[q] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fmaf(x0[k], m0, acc[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = (acc[k] + a1[k]) + (a2[k] + a3[k]);
+    } else {
+      for (long q = q0 + pp; q < q1; q += PP) {
+        const int x = (int)(q % W);
+        const long r = q / W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(v.p + view_off(v, b, y, x) + lp * 4);
+        const float m = rowmul ? rowmul[q] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fmaf(a[k], m, acc[k]);
+      }
     }
   }
   *reinterpret_cast<f32x4*>(sh + threadIdx.x * 4) = acc;
@@ -407,11 +439,16 @@ static int colsum_impl(TView v, int B, int H, int W, int C, const float* scale, 
   if ((C % 4) || C > 256) { dg_set_error("dg_colsum: C must be a multiple of 4 and <= 256"); return DG_ERR_ARG; }
   const long npix = (long)B * H * W;
   int nb = (int)((npix + 255) / 256);
-  if (nb > 1024) nb = 1024;
+  if (nb > 2048) nb = 2048;
   const int ppb = (int)((npix + nb - 1) / nb);
   nb = (int)((npix + ppb - 1) / ppb);
-  hipLaunchKernelGGL(colsum_partial, dim3(nb), dim3(256), 256 * 4 * sizeof(float), st, v, npix, H, W, C / 4, scratch,
-                     ppb, rowmul);
+  const bool flat = v.sY == (long)W * v.sX && v.sB == (long)H * v.sY;
+  if (flat)
+    hipLaunchKernelGGL(colsum_partial<true>, dim3(nb), dim3(256), 256 * 4 * sizeof(float), st, v, npix, H, W, C / 4,
+                       scratch, ppb, rowmul);
+  else
+    hipLaunchKernelGGL(colsum_partial<false>, dim3(nb), dim3(256), 256 * 4 * sizeof(float), st, v, npix, H, W, C / 4,
+                       scratch, ppb, rowmul);
   HIPCHECK(hipGetLastError());
   hipLaunchKernelGGL(colsum_final, dim3(C), dim3(256), 0, st, scratch, nb, C, scale, out, raw, accumulate);
   HIPCHECK(hipGetLastError());

@@ -250,11 +250,8 @@ static int u_conv_bwd(depgan_ctx* c, GLayer& L, size_t li, const float* x_user, 
   TView xin = (li == 0) ? make_view(const_cast<float*>(x_user), L.H, L.W, L.Cin) : L.in;
   TView draw;
   DGCHECK(u_bn_bwd(c, L, dy, L.H, L.W, n, dyscale, &draw));
-  {
-    ProfScope ps(c, 2, 0.0);
-    DGCHECK(dg_colsum(draw, n, L.H, L.W, L.Cout, nullptr, L.db, nullptr, 0, c->scratch, c->st));
-  }
-  DGCHECK(wgrad_full(c, 3, xin, draw, n, L.H, L.W, L.Cin, L.Cout, nullptr, L.dW, nullptr, 0, 0));
+  const ColSum cs = {n, nullptr, L.db, nullptr};
+  DGCHECK(wgrad_full(c, 3, xin, draw, n, L.H, L.W, L.Cin, L.Cout, nullptr, L.dW, nullptr, 0, 0, &cs));
   if (li == 0) return DG_OK;
   ConvArgs a;
   memset(&a, 0, sizeof(a));
@@ -273,11 +270,8 @@ static int u_backward(depgan_ctx* c, const float* x, const float* z, int n) {
     GLayer& L = c->gl[i];
     if (L.kind == G_HEAD) {
       TView dzv = make_view(c->dz, L.H, L.W, 4);
-      DGCHECK(wgrad_full(c, 1, L.in, dzv, n, L.H, L.W, L.Cin, 4, nullptr, L.dW, nullptr, 0, 0));
-      {
-        ProfScope ps(c, 2, 0.0);
-        DGCHECK(dg_colsum(dzv, n, L.H, L.W, 4, nullptr, L.db, nullptr, 0, c->scratch, c->st));
-      }
+      const ColSum cs = {n, nullptr, L.db, nullptr};
+      DGCHECK(wgrad_full(c, 1, L.in, dzv, n, L.H, L.W, L.Cin, 4, nullptr, L.dW, nullptr, 0, 0, &cs));
       ConvArgs a;
       memset(&a, 0, sizeof(a));
       zero_ep(&a.ep);

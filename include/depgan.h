@@ -119,6 +119,7 @@ int depgan_op_conv2d_bwd_data(const float* dy, const float* w_hwio, float* dx, i
                               int Cout, int KS, int path, void* hip_stream);
 int depgan_op_conv2d_wgrad(const float* x, const float* dy, float* dw_hwio, int B, int H, int W, int Cin, int Cout,
                            int KS, void* hip_stream);
+
 /* diagnostics: MFMA conv with per-workgroup phase stamps (16 x u64 per workgroup: start, after first prefetch
  * issue, stage-0 ready, stage-1 ready, MFMAs done, end, realtime ticks, HW_ID) */
 int depgan_op_conv2d_stamps(const float* in, const float* w_hwio, float* out, int B, int H, int W, int Cin, int Cout,
