@@ -25,7 +25,7 @@ class Config(C.Structure):
     _fields_ = [("batch", C.c_int), ("height", C.c_int), ("width", C.c_int), ("nicg", C.c_int),
                 ("first_fm", C.c_int), ("im_thresh", C.c_float), ("delta", C.c_float), ("lrD", C.c_float),
                 ("lrG", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-                ("nc_out", C.c_int)]
+                ("nc_out", C.c_int), ("bf16_weights", C.c_int)]
 
 
 NET_G, NET_D_Y2, NET_D_DEM = 0, 1, 2

@@ -25,10 +25,14 @@ struct Net {
   std::map<std::string, int> index;
   size_t nTrain = 0, nNon = 0;
   float *P = nullptr, *NT = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
+  // bf16-weights mode (BASELINE config 4): P stays the fp32 master that Adam updates; every kernel reads the
+  // compute copy Pq, in which the "/kernel" tensors are rounded to bf16 (RNE) and everything else is P verbatim
+  float* Pq = nullptr;
+  unsigned char* qmask = nullptr;   // 1 where Pq is rounded
   long adam_t = 0;
   float lr = 1e-4f;
   void add(const std::string& name, std::vector<int> shape, bool trainable);
-  float* p(const std::string& name) const;   // parameter pointer (either arena)
+  float* p(const std::string& name) const;   // parameter pointer the kernels read (either arena; Pq when quantised)
   float* g(const std::string& name) const;   // gradient pointer (trainable only)
 };
 

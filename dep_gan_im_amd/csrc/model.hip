@@ -41,7 +41,7 @@ void Net::add(const std::string& name, std::vector<int> shape, bool trainable) {
 }
 float* Net::p(const std::string& name) const {
   const PInfo& pi = params[index.at(name)];
-  return (pi.trainable ? P : NT) + pi.off;
+  return (pi.trainable ? (Pq ? Pq : P) : NT) + pi.off;
 }
 float* Net::g(const std::string& name) const {
   const PInfo& pi = params[index.at(name)];
@@ -69,7 +69,28 @@ static int net_alloc(depgan_ctx* c, Net* n) {
   DGCHECK(dmalloc(c, &n->M, n->nTrain));
   DGCHECK(dmalloc(c, &n->V, n->nTrain));
   DGCHECK(dmalloc(c, &n->NT, n->nNon));
+  if (c->cfg.bf16_weights) {
+    DGCHECK(dmalloc(c, &n->Pq, n->nTrain));
+    std::vector<unsigned char> m(n->nTrain ? n->nTrain : 4, 0);
+    for (const PInfo& pi : n->params) {
+      const std::string& nm = pi.name;
+      if (pi.trainable && nm.size() > 7 && nm.compare(nm.size() - 7, 7, "/kernel") == 0)
+        for (size_t i = 0; i < pi.size; ++i) m[pi.off + i] = 1;
+    }
+    void* q = nullptr;
+    HIPCHECK(hipMalloc(&q, m.size()));
+    c->allocs.push_back(q);
+    HIPCHECK(hipMemcpy(q, m.data(), m.size(), hipMemcpyHostToDevice));
+    n->qmask = (unsigned char*)q;
+  }
   return DG_OK;
+}
+
+// master -> compute copy (bf16-weights mode only)
+static int net_requantize(depgan_ctx* c, Net& n) {
+  if (!n.Pq || n.nTrain == 0) return DG_OK;
+  ProfScope ps(c, 2, 0.0, "bf16 round");
+  return dg_round_bf16_masked(n.P, n.qmask, n.Pq, n.nTrain, c->st);
 }
 
 // ---------------------------------------------------------------------------
@@ -510,6 +531,7 @@ int refresh_generator_bn(depgan_ctx* c) {
 }
 
 int refresh_generator(depgan_ctx* c) {
+  DGCHECK(net_requantize(c, c->g));
   DGCHECK(refresh_generator_bn(c));
   for (size_t i = 0; i < c->gl.size(); ++i) {
     GLayer& L = c->gl[i];
@@ -532,6 +554,7 @@ int refresh_generator(depgan_ctx* c) {
 
 static int refresh_critic(depgan_ctx* c, DNet& D) {
   if (c->dl.empty()) return DG_OK;  // supervised context: no critics
+  DGCHECK(net_requantize(c, D.net));
   for (int l = 0; l < 11; ++l) {
     const DLayer& L = c->dl[l];
     if (D.wpf[l]) DGCHECK(dg_pack_weights(L.pf, D.W[l], L.Cin, L.Cout, 0, 0, 0, nullptr, D.wpf[l], c->st));

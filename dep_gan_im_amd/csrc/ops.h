@@ -86,3 +86,6 @@ int dg_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, 
 
 int dg_scale_copy(const float* in, float* out, size_t n, float s, hipStream_t st);
 int dg_mean_groups(const float* in, float* out, int groups, int per, hipStream_t st);
+
+// dst[i] = mask[i] ? float(bf16_rne(src[i])) : src[i]      (bf16-weights mode: master -> compute copy)
+int dg_round_bf16_masked(const float* src, const unsigned char* mask, float* dst, size_t n, hipStream_t st);

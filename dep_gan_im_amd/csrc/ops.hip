@@ -2,6 +2,7 @@
 // over the contiguous channel axis, reductions as wave-shuffle -> LDS -> a
 // second deterministic pass (no float atomics).
 #include "ops.h"
+#include <hip/hip_bf16.h>
 #include "epilogue.h"
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -783,6 +784,23 @@ __global__ void mean_groups_kernel(const float* __restrict__ in, float* __restri
 }
 int dg_mean_groups(const float* in, float* out, int groups, int per, hipStream_t st) {
   hipLaunchKernelGGL(mean_groups_kernel, dim3(groups), dim3(256), 0, st, in, out, per);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// bf16-weights mode: round the kernels of the fp32 master into the compute copy
+// ---------------------------------------------------------------------------
+__global__ void round_bf16_masked_kernel(const float* __restrict__ src, const unsigned char* __restrict__ mask,
+                                         float* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = src[i];
+    // plain cast: v_cvt_pk_bf16_f32, round-to-nearest-even, NaN stays NaN
+    dst[i] = mask[i] ? __bfloat162float(__float2bfloat16(v)) : v;
+  }
+}
+int dg_round_bf16_masked(const float* src, const unsigned char* mask, float* dst, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(round_bf16_masked_kernel, dim3(nblk(n, 2048)), dim3(256), 0, st, src, mask, dst, n);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }

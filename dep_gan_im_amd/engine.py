@@ -26,7 +26,7 @@ def _torch():
 
 class Engine:
     def __init__(self, batch, height=256, width=256, nicg=1, first_fm=32, im_thresh=0.5, delta=10.0, lrD=1e-4,
-                 lrG=1e-4, beta1=0.0, beta2=0.9, adam_eps=1e-7, device=None, nc_out=1):
+                 lrG=1e-4, beta1=0.0, beta2=0.9, adam_eps=1e-7, device=None, nc_out=1, bf16_weights=False):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.DepganError("dep_gan_im_amd needs a ROCm GPU (MI355X): torch.cuda.is_available() is False")
@@ -34,7 +34,7 @@ class Engine:
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         torch.cuda.set_device(self.device)
         self.cfg = Config(batch, height, width, nicg, first_fm, im_thresh, delta, lrD, lrG, beta1, beta2, adam_eps,
-                          nc_out)
+                          nc_out, 1 if bf16_weights else 0)
         self.batch, self.height, self.width, self.nicg, self.nc_out = batch, height, width, nicg, nc_out
         h = C.c_void_p()
         check(self.lib.depgan_create(C.byref(self.cfg), C.byref(h)), "depgan_create")

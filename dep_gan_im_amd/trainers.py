@@ -83,15 +83,19 @@ class Trainers:
 
 
 def build_trainers(netG, netD_y2, netD_dem, batchSize=16, delta=10.0, lrD=1e-4, lrG=1e-4, IM_TRSH=0.5,
-                   dist=None, device=None):
+                   dist=None, device=None, weights_dtype="float32"):
     """Builds the loss graph of GT:523-598 for the three models and returns a
     Trainers object.  The models are bound to one engine: afterwards their
-    predict()/get_weights()/save() see the trained weights."""
+    predict()/get_weights()/save() see the trained weights.
+    weights_dtype="bfloat16" (BASELINE config 4): kernels are rounded to bf16 before every use, fp32 accumulate,
+    fp32 master weights and Adam state; get_weights() returns the fp32 masters."""
+    if weights_dtype not in ("float32", "bfloat16"):
+        raise ValueError("weights_dtype must be 'float32' or 'bfloat16'")
     H, W, nicg = netG.input_shape
     if tuple(netD_y2.input_shape) != (H, W, 1) or tuple(netD_dem.input_shape) != (H, W, 1):
         raise ValueError("critics must take (%d,%d,1) images" % (H, W))
     eng = Engine(batchSize, H, W, nicg, first_fm=netG.first_fm, im_thresh=IM_TRSH, delta=delta, lrD=lrD, lrG=lrG,
-                 beta1=0.0, beta2=0.9, device=device)
+                 beta1=0.0, beta2=0.9, device=device, bf16_weights=(weights_dtype == "bfloat16"))
     netG._bind(eng, "G")
     netD_y2._bind(eng, "D_y2")
     netD_dem._bind(eng, "D_dem")

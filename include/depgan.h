@@ -32,6 +32,8 @@ typedef struct depgan_config {
   float beta1, beta2, adam_eps; /* Adam(beta_1=0, beta_2=0.9), K.epsilon() (GT:549)    */
   int nc_out;       /* generator head channels: 1 = DEP-GAN (tanh, GT:520); 4 = DEP-UResNet (softmax, UT:583).
                        0 is read as 1.                                                    */
+  int bf16_weights; /* BASELINE config 4: 1 = every "/kernel" tensor is rounded to bf16 (RNE) before use, products
+                       accumulate in fp32, the fp32 master copy and the Adam state stay fp32; 0 = fp32 weights */
 } depgan_config;
 
 enum { DEPGAN_NET_G = 0, DEPGAN_NET_D_Y2 = 1, DEPGAN_NET_D_DEM = 2 };

@@ -398,13 +398,28 @@ def g_grads(PG, PDy2, PDdem, x, y2, z, thr=0.5, nicg=1, dtype=torch.float32):
 # ----------------------------------------------------------------------------
 # The four closures as one stateful object (GT:549-598)
 # ----------------------------------------------------------------------------
+def round_bf16(a):
+    """float32 -> nearest bfloat16 (ties to even) -> float32, on the bit pattern."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).reshape(np.shape(a))
+
+
+def round_kernels_bf16(P):
+    """BASELINE config 4 ("bf16 weights with fp32 accumulate"): the compute copy of a weight dict -- every
+    '/kernel' tensor rounded to bf16, biases / BN parameters / moving statistics untouched."""
+    return OrderedDict((k, round_bf16(v) if k.endswith("/kernel") else v) for k, v in P.items())
+
+
 class OracleTrainers:
     """netD_y2_train / netD_dem_train / netG_no_update / netG_train with the
-    reference's positional contracts; weights are NumPy dicts updated in place."""
+    reference's positional contracts; weights are NumPy dicts updated in place.
+    weights_dtype="bfloat16": gradients are taken at the bf16-rounded kernels and applied to the fp32 masters."""
 
     def __init__(self, PG, PDy2, PDdem, lrD=1e-4, lrG=1e-4, delta=10.0, thr=0.5, nicg=1,
-                 dtype=torch.float32):
-        self.PG, self.PDy2, self.PDdem = PG, PDy2, PDdem
+                 dtype=torch.float32, weights_dtype="float32"):
+        self._PG, self._PDy2, self._PDdem = PG, PDy2, PDdem
+        self._q = round_kernels_bf16 if weights_dtype == "bfloat16" else (lambda P: P)
         self.delta, self.thr, self.nicg, self.dtype = delta, thr, nicg, dtype
         self.optD_y2 = KerasAdam(trainable_names(PDy2), lrD, 0.0, 0.9)   # GT:549
         self.optD_dem = KerasAdam(trainable_names(PDdem), lrD, 0.0, 0.9)  # GT:568
@@ -413,13 +428,13 @@ class OracleTrainers:
     def netD_y2_train(self, inputs):
         y2, x, z, ep = inputs
         outs, grads, _ = critic_grads(self.PDy2, self.PG, y2, x, z, ep, "y2", self.delta, self.nicg, self.dtype)
-        self.optD_y2.apply(self.PDy2, grads)
+        self.optD_y2.apply(self._PDy2, grads)
         return outs
 
     def netD_dem_train(self, inputs):
         y2, x, z, ep = inputs
         outs, grads, _ = critic_grads(self.PDdem, self.PG, y2, x, z, ep, "dem", self.delta, self.nicg, self.dtype)
-        self.optD_dem.apply(self.PDdem, grads)
+        self.optD_dem.apply(self._PDdem, grads)
         return outs
 
     def netG_no_update(self, inputs):
@@ -429,8 +444,21 @@ class OracleTrainers:
     def netG_train(self, inputs):
         x, y2, z = inputs
         outs, grads = g_grads(self.PG, self.PDy2, self.PDdem, x, y2, z, self.thr, self.nicg, self.dtype)
-        self.optG.apply(self.PG, grads)
+        self.optG.apply(self._PG, grads)
         return outs
+
+    # the weights the graph reads: the masters, or their bf16-rounded compute copies
+    @property
+    def PG(self):
+        return self._q(self._PG)
+
+    @property
+    def PDy2(self):
+        return self._q(self._PDy2)
+
+    @property
+    def PDdem(self):
+        return self._q(self._PDdem)
 
 
 # ----------------------------------------------------------------------------

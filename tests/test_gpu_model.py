@@ -317,3 +317,45 @@ def test_best_of_k_multi_eval_equals_k_single_evals(lib):
     from dep_gan_im_amd.trainers import Trainers
     assert Trainers(eng).netG_no_update_many([x, y2, zs]) == single
     eng.close()
+
+
+def test_config4_two_channel_input_bf16_weights(lib):
+    """BASELINE config 4: 2-channel input (FLAIR + map), bf16 weights with fp32 accumulate.  Kernels are rounded to
+    bf16 (RNE) before every use, the fp32 masters and Adam state stay fp32.  Oracle: the same graph evaluated at
+    round_kernels_bf16(weights); tolerance is the fp32 one (1e-3) because both sides multiply the same bf16-valued
+    weights and accumulate in fp32."""
+    import dep_gan_im_amd as dg
+    from oracle import depgan_oracle as O
+    img, B, seed = 64, 2, 51
+    PG = O.init_generator(seed, nicg=2, bias_std=0.05)
+    PD1 = O.init_critic(seed + 1, bias_std=0.05, img=img)
+    PD2 = O.init_critic(seed + 2, bias_std=0.05, img=img)
+    x, y2, z, ep = O.synth_batch(seed + 5, B, img, img, nicg=2)
+    rng = np.random.default_rng(seed)
+    x = (x + 0.02 * rng.uniform(size=x.shape)).astype(np.float32)       # tie-free (see module docstring)
+    y2 = (y2 + 0.02 * rng.uniform(size=y2.shape)).astype(np.float32)
+    nets = [dg.Gen_UNet2D((img, img, 2)), dg.Dis_C2D_FCN1((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1))]
+    for n, P in zip(nets, (PG, PD1, PD2)):
+        n.set_weights(P)
+    tr = dg.build_trainers(*nets, batchSize=B, weights_dtype="bfloat16")
+    eng = tr.engine
+    # masters come back bit-exact; the forward pass uses the rounded kernels
+    w = eng.get_weights("G")
+    assert all(np.array_equal(w[k], PG[k]) for k in PG)
+    attr = eng.g_forward(x, z).cpu().numpy()
+    want_q = O.g_predict(O.round_kernels_bf16(PG), x, z, nicg=2)
+    want_f = O.g_predict(PG, x, z, nicg=2)
+    assert rel(attr, want_q) < 1e-3
+    assert rel(want_f, want_q) > 5 * rel(attr, want_q)                   # the rounding is visible, and we follow it
+    ref = O.OracleTrainers(PG, PD1, PD2, nicg=2, dtype=torch.float64, weights_dtype="bfloat16")
+    for name, args in (("netD_y2_train", [y2, x, z, ep]), ("netD_dem_train", [y2, x, z, ep]),
+                       ("netG_no_update", [x, y2, z]), ("netG_train", [x, y2, z]), ("netG_no_update", [x, y2, z])):
+        got, want = getattr(tr, name)(args), getattr(ref, name)(args)
+        assert srel(got, want) < 3e-3, (name, got, want)
+    lr = 1e-4
+    for net, P in (("G", PG), ("D_y2", PD1), ("D_dem", PD2)):
+        W = eng.get_weights(net)
+        for k in P:                                                      # masters moved by one Adam step each
+            assert float(np.abs(W[k] - P[k]).max()) <= 2.05 * lr, (net, k)
+    with pytest.raises(ValueError):
+        dg.build_trainers(*nets, batchSize=B, weights_dtype="float16")

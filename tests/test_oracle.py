@@ -176,3 +176,31 @@ def test_uresnet_phase1_properties():
     t = torch.tensor([[0.0, 1.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]], dtype=torch.float64)
     want = 0.5 * (-np.log(0.25) - np.log(1e-7))
     assert abs(float(O.keras_categorical_crossentropy_t(p, t)) - want) < 1e-9
+
+
+def test_bf16_weight_rounding_and_master_updates():
+    """BASELINE config 4 in the oracle: round-to-nearest-even on the bit pattern equals torch's bfloat16 cast;
+    only '/kernel' tensors are rounded; the closures read rounded copies but Adam moves the fp32 masters."""
+    a = np.random.default_rng(0).standard_normal(20000).astype(np.float32) * 3
+    np.testing.assert_array_equal(O.round_bf16(a), torch.from_numpy(a).to(torch.bfloat16).float().numpy())
+    tie = np.array([1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8], np.float32)          # exact ties: to even
+    np.testing.assert_array_equal(O.round_bf16(tie), np.array([1.0, 1.0 + 2.0 ** -6], np.float32))
+    PD = O.init_critic(2, bias_std=0.05, img=32)
+    Q = O.round_kernels_bf16(PD)
+    for k in PD:
+        if k.endswith("/kernel"):
+            assert not np.array_equal(Q[k], PD[k]) and np.abs(Q[k] - PD[k]).max() <= np.abs(PD[k]).max() * 2.0 ** -8
+        else:
+            assert Q[k] is PD[k]
+    PG = O.init_generator(1, bias_std=0.05)
+    x, y2, z, ep = O.synth_batch(5, 2, 32, 32)
+    before = {k: v.copy() for k, v in PD.items()}
+    tr = O.OracleTrainers(PG, PD, O.init_critic(3, img=32), weights_dtype="bfloat16")
+    out_q = tr.netD_y2_train([y2, x, z, ep])
+    moved = [k for k in PD if not np.array_equal(PD[k], before[k])]
+    # masters took the Adam step; the two tail biases have an exactly zero WGAN gradient (+1/B per fake, -1/B per
+    # real sample cancel and the penalty has no bias gradient), so they stay
+    assert sorted(set(PD) - set(moved)) == ["dense_1/bias", "dis_9/bias"]
+    assert any(np.abs(PD[k] - O.round_bf16(PD[k])).max() > 0 for k in PD if k.endswith("/kernel"))   # and stay fp32
+    out_f = O.OracleTrainers(PG, dict(before), O.init_critic(3, img=32)).netD_y2_train([y2, x, z, ep])
+    assert out_q != out_f
