@@ -175,6 +175,26 @@ def main():
     torch.cuda.synchronize()
     gf_ms = (time.perf_counter() - t1) / 5 * 1e3
     gf_tf = 23.513e9 * B / (gf_ms * 1e-3) / 1e12
+    # the reference-schedule generator iteration (GT:791-878 steady state): 5 critic-Y2 + 5 critic-DEM
+    # updates, the best-of-10 noise search, one G update = 1013 GFLOP per slice of batch; it consumes 5 batches
+    zs = torch.randn(10, B, 32, 1, device=dev)
+
+    def gen_iteration():
+        for _ in range(5):
+            tr.netD_y2_train([y2, x, z, ep])
+        for _ in range(5):
+            tr.netD_dem_train([y2, x, z, ep])
+        outs = tr.netG_no_update_many([x, y2, zs])
+        best = min(range(10), key=lambda k: outs[k][0])
+        tr.netG_train([x, y2, zs[best]])
+
+    gen_iteration()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(2):
+        gen_iteration()
+    barrier()
+    gi_ms = (time.perf_counter() - t1) / 2 * 1e3
     traffic, traffic_src = pmc_traffic(B)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": traffic,
@@ -188,6 +208,10 @@ def main():
                 "ms_per_step": {"igemm_conv": round(conv_ms / 2, 3), "wgrad": round(wg_ms / 2, 3),
                                 "other": round(ot_ms / 2, 3)},
                 "whole_step_frac": round(GFLOP_PER_SLICE * 1e9 * B / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA, 4),
+                "gen_iteration": {"ms": round(gi_ms, 2), "gflop_per_slice_of_batch": 1013.0,
+                                  "achieved": round(1013.0e9 * B / (gi_ms * 1e-3) / 1e12, 2),
+                                  "epoch_slices_per_s": round(5 * B * world / (gi_ms * 1e-3), 1),
+                                  "unit": "5 critic-Y2 + 5 critic-DEM + best-of-10 + 1 G update (GT:791-878)"},
                 "g_forward": {"ms": round(gf_ms, 3), "achieved": round(gf_tf, 2),
                               "frac": round(gf_tf / PEAK_F32_MFMA, 4), "slices_per_s": round(B / (gf_ms * 1e-3), 1)}}
 

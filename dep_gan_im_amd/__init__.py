@@ -9,3 +9,4 @@ from ._lib import DepganError, load  # noqa: F401
 from .models import Dis_C2D_FCN1, Gen_UNet2D  # noqa: F401
 from .trainers import Trainers, build_trainers  # noqa: F401
 from .engine import Engine  # noqa: F401
+from . import evaluate  # noqa: F401,E402

@@ -17,7 +17,7 @@ EXPORTS = [
     "depgan_g_step", "depgan_apply_adam", "depgan_last_sums", "depgan_profile_enable", "depgan_profile_read",
     "depgan_profile_reset", "depgan_profile_dump", "depgan_op_conv2d", "depgan_op_conv2d_bwd_data", "depgan_op_conv2d_wgrad",
     "depgan_op_maxpool", "depgan_op_conv2d_stamps", "depgan_uresnet_grads", "depgan_uresnet_step",
-    "depgan_uresnet_eval", "depgan_profile_read_bytes", "depgan_g_eval_multi",
+    "depgan_uresnet_eval", "depgan_profile_read_bytes", "depgan_g_eval_multi", "depgan_eval_accumulate", "depgan_eval_counts",
 ]
 
 
@@ -79,6 +79,8 @@ def load():
     lib.depgan_op_conv2d.argtypes = [vp, vp, vp, vp] + [C.c_int] * 8 + [vp]
     lib.depgan_op_conv2d_bwd_data.argtypes = [vp, vp, vp] + [C.c_int] * 7 + [vp]
     lib.depgan_op_conv2d_wgrad.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp]
+    lib.depgan_eval_accumulate.argtypes = [vp, vp, vp, C.c_long, C.c_float, vp]
+    lib.depgan_eval_counts.argtypes = [vp, C.c_int] + [vp] * 7 + [C.c_long, C.c_float, C.POINTER(C.c_longlong), vp]
     lib.depgan_op_maxpool.argtypes = [vp, vp] + [C.c_int] * 4 + [vp]
     lib.depgan_op_conv2d_stamps.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, vp]
     lib.depgan_uresnet_grads.argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint, fp]

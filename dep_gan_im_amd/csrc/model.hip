@@ -1296,4 +1296,31 @@ int depgan_op_maxpool(const float* in, float* out, int B, int Ho, int Wo, int C,
                     (hipStream_t)stream);
 }
 
+// ---- evaluation step after the path (GE:616-807): stateless, caller's stream ----
+int depgan_eval_accumulate(const float* pred, const float* mask, float* acc, long n, float weight, void* stream) {
+  if (!pred || !acc || n < 0) { dg_set_error("eval_accumulate: null argument"); return DG_ERR_ARG; }
+  return dg_eval_accumulate(pred, mask, acc, (size_t)n, weight, (hipStream_t)stream);
+}
+int depgan_eval_counts(const float* x, int nicg, const float* pred, const float* code_real, const float* mask1,
+                       const float* wmh1, const float* mask2, const float* wmh2, const float* prob2, long npix,
+                       float thr, long long out_host[DEPGAN_EVAL_NCOUNT], void* stream) {
+  if (!x || !pred || !out_host || nicg < 1 || npix < 0) { dg_set_error("eval_counts: bad argument"); return DG_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* dev = nullptr;
+  HIPCHECK(hipMalloc((void**)&dev, DEPGAN_EVAL_NCOUNT * sizeof(unsigned long long)));
+  int rc = dg_eval_counts(x, nicg, pred, code_real, mask1, wmh1, mask2, wmh2, prob2, (size_t)npix, thr, dev, st);
+  if (rc == DG_OK) {
+    unsigned long long h[DEPGAN_EVAL_NCOUNT];
+    if (hipMemcpyAsync(h, dev, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+      dg_set_error("eval_counts: copy back failed");
+      rc = DG_ERR_HIP;
+    } else {
+      for (int k = 0; k < DEPGAN_EVAL_NCOUNT; ++k) out_host[k] = (long long)h[k];
+    }
+  }
+  hipFree(dev);
+  return rc;
+}
+
 }  // extern "C"

@@ -89,3 +89,9 @@ int dg_mean_groups(const float* in, float* out, int groups, int per, hipStream_t
 
 // dst[i] = mask[i] ? float(bf16_rne(src[i])) : src[i]      (bf16-weights mode: master -> compute copy)
 int dg_round_bf16_masked(const float* src, const unsigned char* mask, float* dst, size_t n, hipStream_t st);
+
+// evaluation step after the path (GE:616-807)
+int dg_eval_accumulate(const float* pred, const float* mask, float* acc, size_t n, float weight, hipStream_t st);
+int dg_eval_counts(const float* x, int nicg, const float* pred, const float* code_real, const float* mask1,
+                   const float* wmh1, const float* mask2, const float* wmh2, const float* prob2, size_t npix, float thr,
+                   unsigned long long* out_dev, hipStream_t st);

@@ -804,3 +804,83 @@ int dg_round_bf16_masked(const float* src, const unsigned char* mask, float* dst
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
+
+// ---------------------------------------------------------------------------
+// evaluation step after the path (DEP-GAN_testing_4fold.py "GE":616-807)
+// ---------------------------------------------------------------------------
+// acc += weight * pred * mask   (GE:623-625: the running sum of the n_repeat masked predictions)
+__global__ void eval_accumulate_kernel(const float* __restrict__ pred, const float* __restrict__ mask,
+                                       float* __restrict__ acc, size_t n, float weight) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float m = mask ? mask[i] : 1.0f;
+    acc[i] = __fadd_rn(acc[i], __fmul_rn(__fmul_rn(pred[i], m), weight));
+  }
+}
+int dg_eval_accumulate(const float* pred, const float* mask, float* acc, size_t n, float weight, hipStream_t st) {
+  hipLaunchKernelGGL(eval_accumulate_kernel, dim3(nblk(n, 2048)), dim3(256), 0, st, pred, mask, acc, n, weight);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
+// Integer census behind the volume and Dice figures of GE:637-790 (all counts: exact, order-independent).
+//  [0] nnz(mask1*wmh1)  [1] nnz(mask2*wmh2)  [2] #(x >= T, all input channels)  [3] #(prob2 >= T)
+//  [4] nnz(mask2 * [fake > T])            fake = clip(x0 + pred, -1, 1), x0 = channel 0 of x
+//  change code of the prediction: 1 (shrink) fake < T & x0 >= T; 2 (grow) fake >= T & x0 < T; 3 (stay) both >= T
+//  [5+3(k-1) ..] for k = 1,2,3: #(fake_code == k & real_code == k), #(real_code == k), #(fake_code == k)
+//  [14..16] the same for code > 0 (whole WMH), [17..19] for code in {1,2} (changing WMH)
+#define DG_EVAL_NCOUNT 20
+__global__ void eval_counts_kernel(const float* __restrict__ x, int nicg, const float* __restrict__ pred,
+                                   const float* __restrict__ code_real, const float* __restrict__ mask1,
+                                   const float* __restrict__ wmh1, const float* __restrict__ mask2,
+                                   const float* __restrict__ wmh2, const float* __restrict__ prob2, size_t npix,
+                                   float thr, unsigned long long* __restrict__ out) {
+  __shared__ unsigned int sh[DG_EVAL_NCOUNT];
+  if (threadIdx.x < DG_EVAL_NCOUNT) sh[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned int c[DG_EVAL_NCOUNT];
+#pragma unroll
+  for (int k = 0; k < DG_EVAL_NCOUNT; ++k) c[k] = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+    const float x0 = x[i * nicg];
+    float fake = __fadd_rn(x0, pred[i]);
+    fake = fake < -1.0f ? -1.0f : (fake > 1.0f ? 1.0f : fake);
+    if (mask1 && wmh1) c[0] += (__fmul_rn(mask1[i], wmh1[i]) != 0.0f);
+    if (mask2 && wmh2) c[1] += (__fmul_rn(mask2[i], wmh2[i]) != 0.0f);
+    for (int ch = 0; ch < nicg; ++ch) c[2] += (x[i * nicg + ch] >= thr);
+    if (prob2) c[3] += (prob2[i] >= thr);
+    const float m2 = mask2 ? mask2[i] : 1.0f;
+    c[4] += (fake > thr) && (m2 != 0.0f);
+    const bool fhi = fake >= thr, xhi = x0 >= thr;
+    const int fc = (!fhi && xhi) ? 1 : ((fhi && !xhi) ? 2 : ((fhi && xhi) ? 3 : 0));
+    const float rcf = code_real ? code_real[i] : 0.0f;
+#pragma unroll
+    for (int k = 1; k <= 3; ++k) {
+      const bool r = (rcf == (float)k), f = (fc == k);
+      c[5 + 3 * (k - 1)] += (r && f);
+      c[6 + 3 * (k - 1)] += r;
+      c[7 + 3 * (k - 1)] += f;
+    }
+    {
+      const bool r = rcf > 0.0f, f = fc > 0;
+      c[14] += (r && f); c[15] += r; c[16] += f;
+    }
+    {
+      const bool r = (rcf == 1.0f) || (rcf == 2.0f), f = (fc == 1) || (fc == 2);
+      c[17] += (r && f); c[18] += r; c[19] += f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DG_EVAL_NCOUNT; ++k)
+    if (c[k]) atomicAdd(&sh[k], c[k]);       // integer adds: any order gives the same total
+  __syncthreads();
+  if (threadIdx.x < DG_EVAL_NCOUNT && sh[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+}
+int dg_eval_counts(const float* x, int nicg, const float* pred, const float* code_real, const float* mask1,
+                   const float* wmh1, const float* mask2, const float* wmh2, const float* prob2, size_t npix, float thr,
+                   unsigned long long* out_dev, hipStream_t st) {
+  HIPCHECK(hipMemsetAsync(out_dev, 0, DG_EVAL_NCOUNT * sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(eval_counts_kernel, dim3(nblk(npix, 1024)), dim3(256), 0, st, x, nicg, pred, code_real, mask1, wmh1,
+                     mask2, wmh2, prob2, npix, thr, out_dev);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
