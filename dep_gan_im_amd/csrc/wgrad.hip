@@ -15,6 +15,8 @@
 // step is bit-reproducible run to run).
 // A = X^T: lane (r, h) reads channel r of pixel k_h, B: channel r of the same
 // pixel of D -> both are conflict-free 32-bit LDS reads of a [pixel][MF] image.
+#include <stdlib.h>
+
 #include "common.h"
 
 template <int MF>
@@ -38,27 +40,50 @@ struct MfmaW<16> {
   static __device__ __forceinline__ int row(int j, int h) { return 4 * h + j; }
 };
 
+// ---------------------------------------------------------------------------
+// Staging: LDS-DMA (global_load_lds_dwordx4), double-buffered, one workgroup per CU.
+//
+// Nine (or 25) accumulator tiles leave no registers to hold a tile in flight, and with register staging the
+// load and MFMA phases of co-resident workgroups ran in lockstep, so the matrix pipe idled during every staging phase
+// (85 TFLOP/s).  Here the next tile is copied global -> LDS by the DMA path (no VGPR destination, no ds_write pass)
+// into the second of two LDS buffers while the MFMAs of the current tile run: two raw barriers and one counted vmcnt
+// per tile, accumulators in AGPRs, no spills (113-117 TFLOP/s on the 3x3 layers).
+// The LDS image is the [pixel][MF] one of the header, which is lane-linear per wave-instruction (64 lanes x 16 B =
+// 64*16/(4 MF) pixels) as the DMA requires; out-of-image pixels and channel tails read a 16-byte zero constant instead
+// (the per-lane SOURCE address is free), so no lane is ever masked and every wave issues the same number of pieces.
+// ---------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float dg_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+#define DG_GLDS16(src, dst)                                                                               \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                   \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
 template <int MF, int KS, int TPW, int TH>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
-  constexpr int PAD = KS / 2;
-  constexpr int TW = 16 + KS - 1;
-  constexpr int THH = TH + KS - 1;
-  constexpr int PIXT = THH * TW;
-  constexpr int NTAPS = KS * KS;
-  constexpr int NGT = NTAPS / TPW;
-  constexpr int KM = 64 / MF;          // pixels per MFMA
-  constexpr int PW = TH * 4;           // pixels per wave per tile (TH/4 rows of 16)
-  constexpr int KSTEPS = PW / KM;
-  static_assert(KSTEPS % 2 == 0, "k-steps are consumed in pairs");
-  constexpr int V = MF / 4;            // float4 per pixel row in LDS
-  constexpr int XTOT = PIXT * V;
-  constexpr int DTOT = TH * 16 * V;
+struct WDmaCfg {
+  static constexpr int TW = 16 + KS - 1, THH = TH + KS - 1, PIXT = THH * TW, V = MF / 4;
+  static constexpr int XTOT = PIXT * V, DTOT = TH * 16 * V;          // 16-byte pieces per tile
+  static constexpr int NXP = (XTOT + 255) / 256, NDP = DTOT / 256;   // DMA instructions per wave per tile
+  static constexpr int XBUF = NXP * 256 * 4, DBUF = DTOT * 4, BUF = XBUF + DBUF;   // floats
+  static constexpr size_t LDS_TILES = (size_t)2 * BUF * sizeof(float);
+  static constexpr size_t LDS_RED = (size_t)4 * MF * MF * sizeof(float);
+  static constexpr size_t LDS_BYTES = LDS_TILES > LDS_RED ? LDS_TILES : LDS_RED;
+  static_assert(DTOT % 256 == 0, "dy tile must be whole wave-instructions");
+};
+
+template <int MF, int KS, int TPW, int TH>
+__global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
+  typedef WDmaCfg<MF, KS, TPW, TH> C;
+  constexpr int PAD = KS / 2, TW = C::TW, NTAPS = KS * KS, NGT = NTAPS / TPW;
+  constexpr int KM = 64 / MF, PW = TH * 4, KSTEPS = PW / KM, V = C::V;
+  constexpr int XTOT = C::XTOT, NXP = C::NXP, NDP = C::NDP, XBUF = C::XBUF, BUF = C::BUF;
+  constexpr int NPIECE = NXP + NDP;
+  constexpr int NREAD = TPW + 1;                       // LDS reads per k-step
+  constexpr bool COUNTED = NREAD <= 15;                // lgkmcnt is a 4-bit counter
   static_assert(NTAPS % TPW == 0 && (TPW == NTAPS || TPW == KS), "tap grouping");
+  static_assert(NPIECE <= 63, "vmcnt is a 6-bit counter");
   typedef typename MfmaW<MF>::acc_t acc_t;
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;               // [PIXT][MF]
-  float* ds = smem + PIXT * MF;   // [TH*16][MF]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane % MF, h = lane / MF;
@@ -79,27 +104,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < MfmaW<MF>::NREG; ++j) acc[t][j] = 0.f;
 
-  // fp32 MFMA shares the vector ALUs with every VALU instruction on the SIMD, so the tile loop is
-  // written to issue almost none: per-thread staging offsets are computed once per workgroup,
-  // interior tiles skip all bounds logic, and the fully unrolled k-loop reads its fragments with
-  // compile-time LDS offsets from two per-lane base addresses.
-  constexpr int NXP = (XTOT + 255) / 256, NDP = (DTOT + 255) / 256;
-  static_assert((V & (V - 1)) == 0, "channel parts per pixel must be a power of two");
-  int xofs[NXP];              // element offset of piece i relative to the tile origin (may be negative)
+  // per-thread piece geometry, fixed for the whole kernel
+  int xofs[NXP], xyx[NXP];
 #pragma unroll
   for (int i = 0; i < NXP; ++i) {
     const int q = tid + i * 256;
     const int pix = q / V, part = q & (V - 1);
     const int ly = pix / TW, lx = pix - ly * TW;
     xofs[i] = (ly - PAD) * (int)a.x.sY + (lx - PAD) * (int)a.x.sX + part * 4;
+    xyx[i] = (q < XTOT) ? ((ly << 8) | lx) : -1;       // -1: padding piece behind the halo tile
   }
   const int dpart = (tid & (V - 1)) * 4;
   const bool cxok = (ci0 + dpart) < a.Cin, cdok = (co0 + dpart) < a.Cout;
-  // per-lane fragment bases (k-step and tap offsets are compile-time immediates)
-  const float* bbase = ds + ((wv * (TH / 4)) * 16 + h) * MF + r;
-  const float* xbase = xs + ((wv * (TH / 4) + (TPW == NTAPS ? 0 : tg)) * TW + h) * MF + r;
+  const float* zsrc = dg_zero16;
 
-  for (int tile = t0; tile < t1; ++tile) {
+  auto issue = [&](int tile, int buf) {
     int t = tile;
     const int tx0 = (t % tilesX) * 16;
     t /= tilesX;
@@ -108,74 +127,107 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const float* xb = a.x.p + ((long)b * a.x.sB + (long)ty0 * a.x.sY + (long)tx0 * a.x.sX + ci0);
     const float* db = a.dy.p + ((long)b * a.dy.sB + (long)ty0 * a.dy.sY + (long)tx0 * a.dy.sX + co0);
     const bool interior = ty0 >= PAD && ty0 + TH + PAD <= a.H && tx0 >= PAD && tx0 + 16 + PAD <= a.W;
-    __syncthreads();  // previous tile's reads done
-    if (interior) {
+    float* xs = smem + buf * BUF;
+    float* ds = xs + XBUF;
 #pragma unroll
-      for (int i = 0; i < NXP; ++i) {
-        if ((i + 1) * 256 <= XTOT || tid + i * 256 < XTOT) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (cxok) v = *reinterpret_cast<const f32x4*>(xb + xofs[i]);
-          *reinterpret_cast<f32x4*>(xs + (tid + i * 256) * 4) = v;
-        }
+    for (int i = 0; i < NXP; ++i) {
+      bool ok = cxok && xyx[i] >= 0;
+      if (!interior) {
+        const int iy = ty0 + (xyx[i] >> 8) - PAD, ix = tx0 + (xyx[i] & 255) - PAD;
+        ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NXP; ++i) {
-        if ((i + 1) * 256 <= XTOT || tid + i * 256 < XTOT) {
-          const int pix = (tid + i * 256) / V;          // border tiles only: recompute the halo coordinates
-          const int ly = pix / TW, lx = pix - ly * TW;
-          const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (cxok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *reinterpret_cast<const f32x4*>(xb + xofs[i]);
-          *reinterpret_cast<f32x4*>(xs + (tid + i * 256) * 4) = v;
-        }
-      }
+      const float* src = ok ? (xb + xofs[i]) : zsrc;
+      DG_GLDS16(src, xs + (tid + i * 256) * 4);
     }
-    __builtin_amdgcn_sched_barrier(0);  // bound the staging registers: X pieces are in LDS before D loads issue
 #pragma unroll
     for (int i = 0; i < NDP; ++i) {
-      if ((i + 1) * 256 <= DTOT || tid + i * 256 < DTOT) {
-        const int q = tid + i * 256;
-        const int pix = q / V;              // V is a power of two: shifts
-        const int ly = pix >> 4, lx = pix & 15;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (cdok && (interior || (ty0 + ly < a.H && tx0 + lx < a.W)))
-          v = *reinterpret_cast<const f32x4*>(db + (ly * (int)a.dy.sY + lx * (int)a.dy.sX + dpart));
-        *reinterpret_cast<f32x4*>(ds + q * 4) = v;
-      }
+      const int q = tid + i * 256;
+      const int pix = q / V;
+      const int ly = pix >> 4, lx = pix & 15;
+      const bool ok = cdok && (interior || (ty0 + ly < a.H && tx0 + lx < a.W));
+      const float* src = ok ? (db + (ly * (int)a.dy.sY + lx * (int)a.dy.sX + dpart)) : zsrc;
+      DG_GLDS16(src, ds + q * 4);
     }
-    __syncthreads();
-    // Fragments for k-step kk+1 are read from LDS before the MFMAs of step kk issue
-    // (two register sets, static indices), so LDS latency hides under 9 x 64 MFMA cycles.
+  };
+
+  const int fragB = ((wv * (TH / 4)) * 16 + h) * MF + r;   // float offsets inside a buffer's D / X images
+  const int fragX = ((wv * (TH / 4) + (TPW == NTAPS ? 0 : tg)) * TW + h) * MF + r;
+
+  if (t0 < t1) issue(t0, 0);
+  for (int tile = t0; tile < t1; ++tile) {
+    const int buf = (tile - t0) & 1;
+    // every wave has finished the MFMA loop of tile-1 (its LDS reads were consumed by those MFMAs), so the other
+    // buffer may be overwritten
+    __builtin_amdgcn_s_barrier();
+    if (tile + 1 < t1) {
+      issue(tile + 1, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");   // this wave's pieces of `tile` have landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                      // ... and so have everybody else's
     float afr[2][TPW], bfr[2];
-    auto load_frag = [&](int kk, float* av, float& bv) {
-      constexpr int SPR = 16 / KM;                       // k-steps per pixel row
-      const int pyo = kk / SPR, pxo = (kk % SPR) * KM;   // compile-time after unrolling
-      bv = bbase[(pyo * 16 + pxo) * MF];
+    if (COUNTED) {
+      // Fragment reads as inline asm with counted waits: for compiler-visible ds_reads hipcc puts
+      // s_waitcnt lgkmcnt(0) in front of every other MFMA group, which also waits for the reads of the NEXT k-step
+      // issued just before, and with one wave per SIMD nothing hides that LDS latency.  LDS reads retire in order,
+      // so leaving the NREAD newest outstanding means the previous k-step's have arrived; sched_barriers pin
+      // read -> wait -> MFMA.
+      const unsigned bbase =
+          (unsigned)(size_t)(__attribute__((address_space(3))) float*)(smem + buf * BUF + XBUF + fragB);
+      const unsigned xbase = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(smem + buf * BUF + fragX);
+      auto load_frag = [&](int kk, float* av, float& bv) {
+        constexpr int SPR = 16 / KM;
+        const int pyo = kk / SPR, pxo = (kk % SPR) * KM;
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bv) : "v"(bbase), "n"(4 * (pyo * 16 + pxo) * MF));
 #pragma unroll
-      for (int tl = 0; tl < TPW; ++tl) {
-        const int ty = (TPW == NTAPS) ? (tl / KS) : 0;  // row offset already in xbase for row groups
-        const int tx = (TPW == NTAPS) ? (tl % KS) : tl;
-        av[tl] = xbase[((pyo + ty) * TW + pxo + tx) * MF];
+        for (int tl = 0; tl < TPW; ++tl) {
+          const int ty = (TPW == NTAPS) ? (tl / KS) : 0;   // row offset already in fragX for row groups
+          const int tx = (TPW == NTAPS) ? (tl % KS) : tl;
+          asm volatile("ds_read_b32 %0, %1 offset:%2"
+                       : "=v"(av[tl])
+                       : "v"(xbase), "n"(4 * ((pyo + ty) * TW + pxo + tx) * MF));
+        }
+      };
+      load_frag(0, afr[0], bfr[0]);
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        if (kk + 1 < KSTEPS) load_frag(kk + 1, afr[(kk + 1) & 1], bfr[(kk + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 1 < KSTEPS) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(COUNTED ? NREAD : 0) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[kk & 1][tl], bfr[kk & 1], acc[tl]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    };
-    load_frag(0, afr[0], bfr[0]);
+    } else {
+      const float* bbase = smem + buf * BUF + XBUF + fragB;
+      const float* xbase = smem + buf * BUF + fragX;
+      auto load_frag = [&](int kk, float* av, float& bv) {
+        constexpr int SPR = 16 / KM;
+        const int pyo = kk / SPR, pxo = (kk % SPR) * KM;
+        bv = bbase[(pyo * 16 + pxo) * MF];
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk += 2) {
-      load_frag(kk + 1, afr[1], bfr[1]);
-      __builtin_amdgcn_sched_barrier(0);  // keep the reads of step kk+1 ahead of the MFMAs of step kk
+        for (int tl = 0; tl < TPW; ++tl) {
+          const int ty = (TPW == NTAPS) ? (tl / KS) : 0;
+          const int tx = (TPW == NTAPS) ? (tl % KS) : tl;
+          av[tl] = xbase[((pyo + ty) * TW + pxo + tx) * MF];
+        }
+      };
+      load_frag(0, afr[0], bfr[0]);
 #pragma unroll
-      for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[0][tl], bfr[0], acc[tl]);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kk + 2 < KSTEPS) load_frag(kk + 2, afr[0], bfr[0]);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        if (kk + 1 < KSTEPS) load_frag(kk + 1, afr[(kk + 1) & 1], bfr[(kk + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[1][tl], bfr[1], acc[tl]);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[kk & 1][tl], bfr[kk & 1], acc[tl]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
-  // ---- sum the 4 waves through LDS and write one slab per workgroup ----
+  // ---- sum the 4 waves through LDS and write one slab per workgroup (as wgrad_kernel) ----
   float* red = smem;  // [4][MF*MF]
   const size_t slab = (size_t)NTAPS * a.Cin * a.Cout;
   float* pout = a.part + (size_t)chunk * slab;
@@ -187,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     __syncthreads();
     const int tap = tg * TPW + tl;
     for (int e = tid; e < MF * MF; e += 256) {
-      const float s = (red[e] + red[MF * MF + e]) + (red[2 * MF * MF + e] + red[3 * MF * MF + e]);
+      const float sum = (red[e] + red[MF * MF + e]) + (red[2 * MF * MF + e] + red[3 * MF * MF + e]);
       const int ci = ci0 + e / MF, co = co0 + e % MF;
-      if (ci < a.Cin && co < a.Cout) pout[((size_t)tap * a.Cin + ci) * a.Cout + co] = s;
+      if (ci < a.Cin && co < a.Cout) pout[((size_t)tap * a.Cin + ci) * a.Cout + co] = sum;
     }
   }
 }
@@ -214,7 +266,7 @@ static void chunking(const WVar& v, int B, int H, int W, int Cin, int Cout, int*
   const int tilesX = cdiv(W, 16), tilesY = cdiv(H, v.TH);
   *nTiles = B * tilesX * tilesY;
   *gridY = cdiv(Cin, v.MF) * cdiv(Cout, v.MF) * (v.KS * v.KS / v.TPW);
-  int want = 1536 / *gridY;
+  int want = 512 / *gridY;   // one workgroup per CU is resident (two where the tile buffers are small): two rounds
   if (want < 1) want = 1;
   if (want > *nTiles) want = *nTiles;
   *tilesPerChunk = cdiv(*nTiles, want);
@@ -231,18 +283,16 @@ size_t dg_wgrad_part_floats(int KS, int B, int H, int W, int Cin, int Cout) {
 }
 
 template <int MF, int KS, int TPW, int TH>
-static int launch_wgrad(WgradArgs a, int nchunks, int gridY, hipStream_t st) {
-  constexpr int TW = 16 + KS - 1;
-  constexpr size_t lds_tiles = (size_t)((TH + KS - 1) * TW + TH * 16) * MF * sizeof(float);
-  constexpr size_t lds_red = (size_t)4 * MF * MF * sizeof(float);
-  constexpr size_t lds = lds_tiles > lds_red ? lds_tiles : lds_red;
+static int launch_wgrad_dma(WgradArgs a, int nchunks, int gridY, hipStream_t st) {
+  constexpr size_t lds = WDmaCfg<MF, KS, TPW, TH>::LDS_BYTES;
+  static_assert(lds <= 160 * 1024, "two tile buffers must fit the CU's LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<MF, KS, TPW, TH>),
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<MF, KS, TPW, TH>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<MF, KS, TPW, TH>), dim3(nchunks, gridY), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((wgrad_dma_kernel<MF, KS, TPW, TH>), dim3(nchunks, gridY), dim3(256), lds, st, a);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
@@ -261,12 +311,12 @@ int dg_wgrad(int KS, const WgradArgs& a_in, int* nchunks_out, hipStream_t st) {
   a.nTiles = nTiles;
   a.tilesPerChunk = tpc;
   *nchunks_out = nch;
-  if (KS == 3 && v.MF == 32) return launch_wgrad<32, 3, 9, 16>(a, nch, gy, st);
-  if (KS == 3 && v.MF == 16) return launch_wgrad<16, 3, 9, 16>(a, nch, gy, st);
-  if (KS == 5 && v.MF == 32) return launch_wgrad<32, 5, 5, 8>(a, nch, gy, st);
-  if (KS == 5 && v.MF == 16) return launch_wgrad<16, 5, 25, 16>(a, nch, gy, st);
-  if (KS == 1 && v.MF == 32) return launch_wgrad<32, 1, 1, 16>(a, nch, gy, st);
-  if (KS == 1 && v.MF == 16) return launch_wgrad<16, 1, 1, 16>(a, nch, gy, st);
+  if (KS == 3 && v.MF == 32) return launch_wgrad_dma<32, 3, 9, 16>(a, nch, gy, st);
+  if (KS == 3 && v.MF == 16) return launch_wgrad_dma<16, 3, 9, 16>(a, nch, gy, st);
+  if (KS == 5 && v.MF == 32) return launch_wgrad_dma<32, 5, 5, 8>(a, nch, gy, st);
+  if (KS == 5 && v.MF == 16) return launch_wgrad_dma<16, 5, 25, 16>(a, nch, gy, st);
+  if (KS == 1 && v.MF == 32) return launch_wgrad_dma<32, 1, 1, 16>(a, nch, gy, st);
+  if (KS == 1 && v.MF == 16) return launch_wgrad_dma<16, 1, 1, 16>(a, nch, gy, st);
   dg_set_error("dg_wgrad: unsupported kernel size %d", KS);
   return DG_ERR_UNSUPPORTED;
 }
