@@ -226,43 +226,58 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
       es[pl * CP + r] = acc[mt][j];
     }
   }
+  // On a SIMD nothing that is issued overlaps with fp32 MFMAs, so the epilogue is written for
+  // instruction count: every operand test is a scalar branch on a kernel argument, and every access is
+  // (uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset computed once) so that the loads and stores take the
+  // saddr form and the per-pass address arithmetic is a handful of scalar adds.
   constexpr int LPP = NT / 4;     // lanes per pixel
-  constexpr int PPP = 64 / LPP;   // pixels per pass
+  constexpr int PPP = 64 / LPP;   // pixels per pass (8 for NT = 32: half a tile row; 16 for NT = 16: one row)
   constexpr int NPASS = 64 / PPP;
   const int c4 = (lane % LPP) * 4, pl0 = lane / LPP;
   const int co = n0 + c4;
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
+  const Epilogue& e = a.ep;
+  const bool affine = e.scale != nullptr, film = e.film_mul != nullptr, relu = e.relu != 0, accum = e.accumulate != 0;
+  const bool has_bias = e.bias != nullptr, has_pre = e.out_pre.p != nullptr, has_res = e.res.p != nullptr,
+             has_msk = e.mask.p != nullptr;
+  const int oyw = ty0 + 4 * wvu;
+  const bool full = (ty0 + 16 <= a.H) && (tx0 + 16 <= a.W);
   if (co < a.Cout) {
-    const Epilogue& e = a.ep;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
-    const f32x4 bias4 = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + co) : zero4;
-    const bool affine = e.scale != nullptr, film = e.film_mul != nullptr, relu = e.relu != 0,
-               accum = e.accumulate != 0;
-    const f32x4 sc4 = affine ? *reinterpret_cast<const f32x4*>(e.scale + co) : one4;
-    const f32x4 sh4 = affine ? *reinterpret_cast<const f32x4*>(e.shift + co) : zero4;
-    const f32x4 fm4 = film ? *reinterpret_cast<const f32x4*>(e.film_mul + (long)b * e.film_ld + co) : one4;
-    const f32x4 fa4 = film ? *reinterpret_cast<const f32x4*>(e.film_add + (long)b * e.film_ld + co) : zero4;
-    const int oyw = ty0 + 4 * wv;
-    const bool full = (ty0 + 16 <= a.H) && (tx0 + 16 <= a.W);
-    float* pout = a.out.p + view_off(a.out, b, oyw, tx0) + co;
-    const int oSY = (int)a.out.sY, oSX = (int)a.out.sX;
-    float* ppre = e.out_pre.p ? e.out_pre.p + view_off(e.out_pre, b, oyw, tx0) + co : nullptr;
-    const int pSY = (int)e.out_pre.sY, pSX = (int)e.out_pre.sX;
-    const float* pres = e.res.p ? e.res.p + view_off(e.res, b, oyw, tx0) + co : nullptr;
-    const int rSY = (int)e.res.sY, rSX = (int)e.res.sX;
-    const float* pmsk = e.mask.p ? e.mask.p + view_off(e.mask, b, oyw, tx0) + co : nullptr;
-    const int mSY = (int)e.mask.sY, mSX = (int)e.mask.sX;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 fm4 = {1.f, 1.f, 1.f, 1.f}, fa4 = {0.f, 0.f, 0.f, 0.f};
+    if (has_bias) bias4 = *reinterpret_cast<const f32x4*>(e.bias + co);
+    if (affine) {
+      sc4 = *reinterpret_cast<const f32x4*>(e.scale + co);
+      sh4 = *reinterpret_cast<const f32x4*>(e.shift + co);
+    }
+    if (film) {
+      fm4 = *reinterpret_cast<const f32x4*>(e.film_mul + (long)b * e.film_ld + co);
+      fa4 = *reinterpret_cast<const f32x4*>(e.film_add + (long)b * e.film_ld + co);
+    }
+    // per-lane byte offsets inside a pass (pixel pl0 of the pass, channel co), one per view
+    const unsigned lo_out = 4u * (unsigned)(pl0 * (int)a.out.sX + co);
+    const unsigned lo_pre = has_pre ? 4u * (unsigned)(pl0 * (int)e.out_pre.sX + co) : 0u;
+    const unsigned lo_res = has_res ? 4u * (unsigned)(pl0 * (int)e.res.sX + co) : 0u;
+    const unsigned lo_msk = has_msk ? 4u * (unsigned)(pl0 * (int)e.mask.sX + co) : 0u;
+    // uniform bases of pass 0: pixel (oyw, tx0) of sample b
+    const char* ub_out = reinterpret_cast<const char*>(a.out.p + view_off(a.out, b, oyw, tx0));
+    const char* ub_pre = has_pre ? reinterpret_cast<const char*>(e.out_pre.p + view_off(e.out_pre, b, oyw, tx0)) : nullptr;
+    const char* ub_res = has_res ? reinterpret_cast<const char*>(e.res.p + view_off(e.res, b, oyw, tx0)) : nullptr;
+    const char* ub_msk = has_msk ? reinterpret_cast<const char*>(e.mask.p + view_off(e.mask, b, oyw, tx0)) : nullptr;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      const int pl = p * PPP + pl0;
-      const int py = pl >> 4, px = pl & 15;
-      if (!full && (oyw + py >= a.H || tx0 + px >= a.W)) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(es + pl * CP + c4);
+      // pass p covers pixels (py, px0 .. px0 + PPP) of the wave's 4 x 16 block
+      const int py = (p * PPP) >> 4, px0 = (p * PPP) & 15;
+      if (!full && (oyw + py >= a.H || tx0 + px0 + pl0 >= a.W)) continue;
+      const long d_out = 4 * ((long)py * a.out.sY + (long)px0 * a.out.sX);   // scalar
+      f32x4 v = *reinterpret_cast<const f32x4*>(es + (p * PPP + pl0) * CP + c4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         v[k] += bias4[k];
         if (affine) v[k] = __fadd_rn(__fmul_rn(v[k], sc4[k]), sh4[k]);
       }
-      if (ppre) *reinterpret_cast<f32x4*>(ppre + (py * pSY + px * pSX)) = v;
+      if (has_pre)
+        *reinterpret_cast<f32x4*>(const_cast<char*>(ub_pre) + 4 * ((long)py * e.out_pre.sY + (long)px0 * e.out_pre.sX) + lo_pre) = v;
       if (film) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = film_preact(v[k], fm4[k], fa4[k]);
@@ -271,17 +286,17 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
       }
-      if (pres) {
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(pres + (py * rSY + px * rSX));
+      if (has_res) {
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(ub_res + 4 * ((long)py * e.res.sY + (long)px0 * e.res.sX) + lo_res);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] += rr[k];
       }
-      if (pmsk) {
-        const f32x4 mm = *reinterpret_cast<const f32x4*>(pmsk + (py * mSY + px * mSX));
+      if (has_msk) {
+        const f32x4 mm = *reinterpret_cast<const f32x4*>(ub_msk + 4 * ((long)py * e.mask.sY + (long)px0 * e.mask.sX) + lo_msk);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = (mm[k] > 0.f) ? v[k] : 0.f;
       }
-      f32x4* o = reinterpret_cast<f32x4*>(pout + (py * oSY + px * oSX));
+      f32x4* o = reinterpret_cast<f32x4*>(const_cast<char*>(ub_out) + d_out + lo_out);
       if (accum) {
         const f32x4 old = *o;
 #pragma unroll
