@@ -59,9 +59,13 @@ class DataParallel:
         return self._views[key]
 
     def _allreduce_grads(self, engine, net):
+        # losses are batch means (GT:540-545, 576): the global gradient is the mean of the rank gradients
         g = self._grad_tensor(engine, net)
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-        g.mul_(1.0 / self.world)   # losses are batch means (GT:540-545, 576)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)    # RCCL averages inside the collective
+        else:                                                            # gloo (CPU tests) has no AVG
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            g.mul_(1.0 / self.world)
 
     def _allreduce_sums(self, engine, n):
         s = torch.tensor(engine.last_sums()[:n], dtype=torch.float64)
