@@ -19,5 +19,4 @@ for _ in range(N):
     lib.depgan_op_conv2d(P(x),P(w),P(b),P(out),B,H,W,ci,co,k,1,1,None)
 torch.cuda.synchronize()
 us = (time.perf_counter() - t0) / N * 1e6
-print("conv k%d b%d %dx%d %d->%d: %.1f us  %.1f TF/s  (DMA=%s stagger=%s)" % (k, B, H, W, ci, co, us, 2.0*B*H*W*ci*co*k*k/us/1e6,
-      os.environ.get("DEPGAN_IGEMM_DMA", "1"), os.environ.get("DEPGAN_DMA_STAGGER", "default")))
+print("conv k%d b%d %dx%d %d->%d: %.1f us  %.1f TF/s (pack + conv per call)" % (k, B, H, W, ci, co, us, 2.0*B*H*W*ci*co*k*k/us/1e6))
