@@ -87,12 +87,27 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     dbg[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
   }
   const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + 15) >> 4;
-  int t = blockIdx.x;
+  // Workgroup -> (pixel tile, channel tile).  Workgroup ids are dealt round-robin over the 8 XCDs (each with its own
+  // L2) in dispatch order.  The channel tiles of one pixel tile read the same halo tile, so they are given to the same
+  // XCD at consecutive dispatch slots: id = 8 s + x  ->  channel tile s % nNT of pixel tile 8 (s / nNT) + x.
+  int t, ntile;
+  {
+    const unsigned nNT = gridDim.y, nPix = gridDim.x;
+    const unsigned id = blockIdx.x + blockIdx.y * nPix;
+    if ((nPix & 7u) == 0 && nNT > 1) {
+      const unsigned x = id & 7u, sl = id >> 3;
+      ntile = (int)(sl % nNT);
+      t = (int)(8u * (sl / nNT) + x);
+    } else {
+      t = (int)blockIdx.x;
+      ntile = (int)blockIdx.y;
+    }
+  }
   const int tx0 = (t % tilesX) * 16;
   t /= tilesX;
   const int ty0 = (t % tilesY) * 16;
   const int b = t / tilesY;
-  const int n0 = blockIdx.y * NT;
+  const int n0 = ntile * NT;
   const int nCC = (a.Cin + CK - 1) / CK;
   const int NS = nCC * NG;
   const float* inb = a.in.p + (long)b * a.in.sB;
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
         xr[i] = v;
       }
     }
-    const float* wsrc = a.w + ((size_t)((size_t)blockIdx.y * nCC + cc) * NTAPS + (size_t)tg * TAPG) * (NT * CK);
+    const float* wsrc = a.w + ((size_t)((size_t)ntile * nCC + cc) * NTAPS + (size_t)tg * TAPG) * (NT * CK);
 #pragma unroll
     for (int i = 0; i < WPIECES; ++i) {
       const int q = tid + i * 256;

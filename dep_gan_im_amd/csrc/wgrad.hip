@@ -88,12 +88,26 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane % MF, h = lane / MF;
   const int nCoT = (a.Cout + MF - 1) / MF;
-  int y = blockIdx.y;
+  // Workgroup -> (pixel-tile chunk, channel-tile pair).  All channel-tile pairs of one chunk read the same x / dy
+  // tiles; workgroup ids are dealt round-robin over the 8 XCDs (own L2 each), so the pairs of a chunk are given to one
+  // XCD at consecutive dispatch slots: id = 8 s + x  ->  pair s % gridDim.y of chunk 8 (s / gridDim.y) + x.
+  int y, chunk;
+  {
+    const unsigned nY = gridDim.y, nX = gridDim.x;
+    const unsigned id = blockIdx.x + blockIdx.y * nX;
+    if ((nX & 7u) == 0 && nY > 1) {
+      const unsigned x = id & 7u, sl = id >> 3;
+      y = (int)(sl % nY);
+      chunk = (int)(8u * (sl / nY) + x);
+    } else {
+      y = (int)blockIdx.y;
+      chunk = (int)blockIdx.x;
+    }
+  }
   const int tg = y % NGT;
   y /= NGT;
   const int co0 = (y % nCoT) * MF;
   const int ci0 = (y / nCoT) * MF;
-  const int chunk = blockIdx.x;
   const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + TH - 1) / TH;
   const int t0 = chunk * a.tilesPerChunk;
   const int t1 = min(t0 + a.tilesPerChunk, a.nTiles);
