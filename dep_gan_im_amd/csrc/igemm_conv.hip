@@ -88,16 +88,17 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
   }
   const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + 15) >> 4;
   // Workgroup -> (pixel tile, channel tile).  Workgroup ids are dealt round-robin over the 8 XCDs (each with its own
-  // L2) in dispatch order.  The channel tiles of one pixel tile read the same halo tile, so they are given to the same
-  // XCD at consecutive dispatch slots: id = 8 s + x  ->  channel tile s % nNT of pixel tile 8 (s / nNT) + x.
+  // L2) in dispatch order.  The channel tiles of one pixel tile read the same halo tile and neighbouring pixel tiles
+  // share two halo columns / rows, so XCD x gets a contiguous eighth of the pixel tiles and walks it with the channel
+  // tile fastest: id = 8 s + x  ->  channel tile s % nNT of pixel tile x (nPix / 8) + s / nNT.
   int t, ntile;
   {
     const unsigned nNT = gridDim.y, nPix = gridDim.x;
     const unsigned id = blockIdx.x + blockIdx.y * nPix;
-    if ((nPix & 7u) == 0 && nNT > 1) {
+    if ((nPix & 7u) == 0) {
       const unsigned x = id & 7u, sl = id >> 3;
       ntile = (int)(sl % nNT);
-      t = (int)(8u * (sl / nNT) + x);
+      t = (int)(x * (nPix >> 3) + sl / nNT);
     } else {
       t = (int)blockIdx.x;
       ntile = (int)blockIdx.y;
