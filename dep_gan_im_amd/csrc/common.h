@@ -73,10 +73,14 @@ struct ConvArgs {
   long wsT, wsI, wsO;
   int flip;
   int vec4;  // direct kernel: all output-side views 16-byte aligned (set by the launcher)
-  // igemm only: first-wave start stagger (shader cycles; 0 = off) and number of workgroups it applies to
-  int stagger, stagger_wgs;
   // diagnostics: when non-null, thread 0 of every workgroup writes 8 x u64 phase stamps here
   unsigned long long* dbg;
+  // igemm only: grouped launch.  groups > 1 runs `groups` convolutions that share the input and the epilogue
+  // constants in ONE launch (the 4 taps of a 2x2 / stride-2 transposed convolution): group g uses the packed weights
+  // w_group[g] and writes to out.p + out_group_off[g]; `w` is ignored.  0 or 1: a single convolution.
+  int groups;
+  const float* w_group[4];
+  long out_group_off[4];
 };
 
 struct WgradArgs {

@@ -69,17 +69,6 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
   float* ws = smem + PIXT * CKP;   // [TAPG][NT][CKP]
 
   const int tid = threadIdx.x;
-  // De-phase the first wave of workgroups: identical workgroups launched together run in
-  // lock-step chip-wide, so their load / store bursts serialise with the MFMA phases.
-  if (a.stagger > 0) {
-    const unsigned id = blockIdx.x + blockIdx.y * gridDim.x;
-    if (id < (unsigned)a.stagger_wgs) {
-      const float ph = (float)id * 0.6180339887f;
-      const long wait = (long)((ph - floorf(ph)) * (float)a.stagger);
-      const long t0 = __builtin_amdgcn_s_memtime();
-      while ((long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
-  }
   unsigned long long* dbg = a.dbg ? a.dbg + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 16 : nullptr;
   if (dbg && tid == 0) {
     dbg[0] = __builtin_amdgcn_s_memtime();
@@ -108,6 +97,13 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
   t /= tilesX;
   const int ty0 = (t % tilesY) * 16;
   const int b = t / tilesY;
+  // grouped launch: the channel-tile index also enumerates the groups (taps of a transposed convolution)
+  const int ngrp = a.groups > 1 ? a.groups : 1;
+  const int nNTg = (int)gridDim.y / ngrp;
+  const int grp = ntile / nNTg;
+  ntile -= grp * nNTg;
+  const float* wbase = a.groups > 1 ? a.w_group[grp] : a.w;
+  const long out_goff = a.groups > 1 ? a.out_group_off[grp] : 0;
   const int n0 = ntile * NT;
   const int nCC = (a.Cin + CK - 1) / CK;
   const int NS = nCC * NG;
@@ -134,7 +130,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
         xr[i] = v;
       }
     }
-    const float* wsrc = a.w + ((size_t)((size_t)ntile * nCC + cc) * NTAPS + (size_t)tg * TAPG) * (NT * CK);
+    const float* wsrc = wbase + ((size_t)((size_t)ntile * nCC + cc) * NTAPS + (size_t)tg * TAPG) * (NT * CK);
 #pragma unroll
     for (int i = 0; i < WPIECES; ++i) {
       const int q = tid + i * 256;
@@ -276,7 +272,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     const unsigned lo_res = has_res ? 4u * (unsigned)(pl0 * (int)e.res.sX + co) : 0u;
     const unsigned lo_msk = has_msk ? 4u * (unsigned)(pl0 * (int)e.mask.sX + co) : 0u;
     // uniform bases of pass 0: pixel (oyw, tx0) of sample b
-    const char* ub_out = reinterpret_cast<const char*>(a.out.p + view_off(a.out, b, oyw, tx0));
+    const char* ub_out = reinterpret_cast<const char*>(a.out.p + out_goff + view_off(a.out, b, oyw, tx0));
     const char* ub_pre = has_pre ? reinterpret_cast<const char*>(e.out_pre.p + view_off(e.out_pre, b, oyw, tx0)) : nullptr;
     const char* ub_res = has_res ? reinterpret_cast<const char*>(e.res.p + view_off(e.res, b, oyw, tx0)) : nullptr;
     const char* ub_msk = has_msk ? reinterpret_cast<const char*>(e.mask.p + view_off(e.mask, b, oyw, tx0)) : nullptr;
@@ -378,31 +374,14 @@ static int launch_variant(const ConvArgs& a, hipStream_t st) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid((unsigned)(cdiv(a.W, 16) * cdiv(a.H, 16) * a.B), (unsigned)cdiv(a.Cout, MF));
+  dim3 grid((unsigned)(cdiv(a.W, 16) * cdiv(a.H, 16) * a.B), (unsigned)(cdiv(a.Cout, MF) * (a.groups > 1 ? a.groups : 1)));
   hipLaunchKernelGGL((igemm_conv_kernel<MF, KS, CK, TAPG>), grid, dim3(256), lds, st, a);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
 
-static float stagger_factor() {
-  static float f = -1.f;
-  if (f < 0.f) {
-    const char* e = getenv("DEPGAN_STAGGER");
-    f = e ? (float)atof(e) : 0.0f;
-  }
-  return f;
-}
-
 int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
   ConvArgs a = a_in;
-  {
-    // one wave issues K MFMAs of 64 cycles per workgroup; ~3 workgroups share a SIMD
-    const float f = stagger_factor();
-    const long K = (long)pl.KS * pl.KS * pl.nCC * pl.CK;
-    const long nwg = (long)cdiv(a.W, 16) * cdiv(a.H, 16) * a.B * cdiv(a.Cout, pl.MF);
-    a.stagger = (f > 0.f && nwg > 1536) ? (int)(f * 192.f * (float)K * (pl.MF == 16 ? 0.5f : 1.f)) : 0;
-    a.stagger_wgs = 768;
-  }
   if (pl.variant < 0) {
     dg_set_error("dg_conv_igemm: no MFMA variant for KS=%d Cin=%d Cout=%d", pl.KS, pl.Cin, pl.Cout);
     return DG_ERR_UNSUPPORTED;

@@ -98,14 +98,15 @@ static int net_requantize(depgan_ctx* c, Net& n) {
 // ---------------------------------------------------------------------------
 
 int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
-  const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cin * a.Cout * KS * KS;
+  const int ng = a.groups > 1 ? a.groups : 1;
+  const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cin * a.Cout * KS * KS * ng;
   char lb[56];
-  snprintf(lb, sizeof(lb), "conv k%d b%d %dx%d %d->%d", KS, a.B, a.H, a.W, a.Cin, a.Cout);
+  snprintf(lb, sizeof(lb), "conv k%d b%d %dx%d %d->%d%s", KS, a.B, a.H, a.W, a.Cin, a.Cout, ng > 1 ? " x4" : "");
   // algorithmic bytes: every operand the epilogue names read once, every result written once, weights once
   const double px = 4.0 * a.B * a.H * a.W;
-  const double by = px * a.Cin + px * a.Cout * (1 + (a.ep.res.p ? 1 : 0) + (a.ep.mask.p ? 1 : 0) +
-                                                (a.ep.out_pre.p ? 1 : 0) + (a.ep.accumulate ? 1 : 0)) +
-                    4.0 * KS * KS * a.Cin * a.Cout;
+  const double by = px * a.Cin + ng * (px * a.Cout * (1 + (a.ep.res.p ? 1 : 0) + (a.ep.mask.p ? 1 : 0) +
+                                                      (a.ep.out_pre.p ? 1 : 0) + (a.ep.accumulate ? 1 : 0)) +
+                                          4.0 * KS * KS * a.Cin * a.Cout);
   if (pl.variant >= 0) {
     ProfScope ps(c, 0, fl, lb, by);
     return dg_conv_igemm(pl, a, c->st);
@@ -599,17 +600,22 @@ int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u
       ProfScope ps(c, 2, 0.0);
       DGCHECK(dg_maxpool(c->gl[L.skip_of].out, L.out, n, L.H / 2, L.W / 2, L.Cout, c->st));
     } else if (L.kind == G_DECONV) {
+      // 2x2 / stride-2 transposed convolution = four 1x1 convolutions of the same input, tap (di, dj) writing the
+      // pixel grid (2i+di, 2j+dj): one grouped launch, the input tile is fetched once per XCD
+      ConvArgs a;
+      memset(&a, 0, sizeof(a));
+      zero_ep(&a.ep);
+      a.in = L.in;
+      a.out = strided2(L.out, 0, 0);
+      a.B = n; a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Cout = L.Cout;
+      a.ep.bias = L.b; a.ep.scale = L.s; a.ep.shift = L.t; a.ep.relu = 1;
+      a.groups = 4;
       for (int t = 0; t < 4; ++t) {
-        ConvArgs a;
-        memset(&a, 0, sizeof(a));
-        zero_ep(&a.ep);
-        a.in = L.in;
-        a.out = strided2(L.out, t / 2, t % 2);
-        a.B = n; a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Cout = L.Cout;
-        a.ep.bias = L.b; a.ep.scale = L.s; a.ep.shift = L.t; a.ep.relu = 1;
-        a.w = L.wpf[t];
-        DGCHECK(conv_launch(c, L.pf, a, 1));
+        a.w_group[t] = L.wpf[t];
+        a.out_group_off[t] = strided2(L.out, t / 2, t % 2).p - a.out.p;
       }
+      a.w = L.wpf[0];
+      DGCHECK(conv_launch(c, L.pf, a, 1));
     } else if (L.kind == G_HEAD && c->cfg.nc_out == 1) {
       ProfScope ps(c, 2, 0.0);
       DGCHECK(dg_head_fwd(L.in.p, L.Wt, L.b, c->attr.p, (long)n * L.H * L.W, L.Cin, 1, c->st));
