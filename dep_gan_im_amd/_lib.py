@@ -47,6 +47,10 @@ def load():
         raise DepganError(
             "libdepgan.so not found at %s -- the HIP library is the product; build it with "
             "`python -m dep_gan_im_amd.build` (needs hipcc). There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime.  It must be in the process BEFORE libdepgan.so is loaded, so that the
+    # library binds to that runtime: loaded the other way round, two runtimes coexist and hipMalloc inside the
+    # library reports "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     fp, vp, ip = C.POINTER(C.c_float), C.c_void_p, C.POINTER(C.c_int)
     lib.depgan_last_error.restype = C.c_char_p
