@@ -5,6 +5,7 @@ it travels with the source tree (it is git-ignored, not gpurun-ignored).
 """
 from __future__ import annotations
 
+import fcntl
 import os
 import subprocess
 import sys
@@ -33,6 +34,18 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
+    """Compile what is stale and link.  Safe to call from several processes at once (one rank per GPU under
+    torch.distributed.run): an exclusive file lock serialises them, objects and the library are replaced atomically."""
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "depgan.h"))
     objdir = os.path.join(HERE, "build")
@@ -47,17 +60,24 @@ def build(force=False, verbose=False):
             jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
 
     def run(cmd):
+        # the output is written next to its final name and renamed, so a reader never sees a partial file
+        out = cmd[-1] if cmd[-2] == "-o" else cmd[cmd.index("-o") + 1]
+        tmp = out + ".tmp%d" % os.getpid()
+        real = [tmp if c == out else c for c in cmd]
         if verbose:
             print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        r = subprocess.run(real, capture_output=True, text=True)
         if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        os.replace(tmp, out)
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB])
     return LIB
 
 
