@@ -21,7 +21,8 @@ static inline int t_nblk(size_t n, int cap) {
 }
 
 // MODE 0: (sum x, -)   MODE 1: (sum (x-m)^2, -)   MODE 2: (sum d, sum d*(x-m))   [v = d, w = x]
-template <int MODE>
+// FLAT: both views are pixel-contiguous (sY == W*sX, sB == H*sY), so pixel q sits at q*sX: no divisions in the loop.
+template <int MODE, bool FLAT>
 __global__ void colsum2_partial(TView v, TView w, const float* __restrict__ m, long npix, int H, int W, int C4,
                                 float* __restrict__ part, int pixPerBlock) {
   extern __shared__ __attribute__((aligned(16))) float sh[];  // [256][8]
@@ -33,11 +34,19 @@ __global__ void colsum2_partial(TView v, TView w, const float* __restrict__ m, l
     f32x4 mv = {0.f, 0.f, 0.f, 0.f};
     if (MODE >= 1) mv = *reinterpret_cast<const f32x4*>(m + lp * 4);
     for (long q = q0 + pp; q < q1; q += PP) {
-      const int x = (int)(q % W);
-      const long r = q / W;
-      const int y = (int)(r % H);
-      const int b = (int)(r / H);
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(v.p + view_off(v, b, y, x) + lp * 4);
+      long ov, ow;
+      if (FLAT) {
+        ov = q * v.sX;
+        ow = q * w.sX;
+      } else {
+        const int x = (int)(q % W);
+        const long r = q / W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        ov = view_off(v, b, y, x);
+        ow = (MODE == 2) ? view_off(w, b, y, x) : 0;
+      }
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(v.p + ov + lp * 4);
       if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) a0[k] += xv[k];
@@ -48,7 +57,7 @@ __global__ void colsum2_partial(TView v, TView w, const float* __restrict__ m, l
           a0[k] = fmaf(d, d, a0[k]);
         }
       } else {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(w.p + view_off(w, b, y, x) + lp * 4);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w.p + ow + lp * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           a0[k] += xv[k];
@@ -91,12 +100,21 @@ static int colsum2_launch(int mode, TView v, TView w, const float* m, int B, int
   const int ppb = (int)((npix + nb - 1) / nb);
   nb = (int)((npix + ppb - 1) / ppb);
   const size_t lds = 256 * 8 * sizeof(float);
-  if (mode == 0)
-    hipLaunchKernelGGL(colsum2_partial<0>, dim3(nb), dim3(256), lds, st, v, w, m, npix, H, W, C / 4, scratch, ppb);
-  else if (mode == 1)
-    hipLaunchKernelGGL(colsum2_partial<1>, dim3(nb), dim3(256), lds, st, v, w, m, npix, H, W, C / 4, scratch, ppb);
-  else
-    hipLaunchKernelGGL(colsum2_partial<2>, dim3(nb), dim3(256), lds, st, v, w, m, npix, H, W, C / 4, scratch, ppb);
+  auto is_flat = [&](const TView& t) { return !t.p || (t.sY == (long)W * t.sX && t.sB == (long)H * t.sY); };
+  const bool flat = is_flat(v) && is_flat(w);
+#define DG_CS2(MODE)                                                                                                  \
+  do {                                                                                                                 \
+    if (flat)                                                                                                          \
+      hipLaunchKernelGGL((colsum2_partial<MODE, true>), dim3(nb), dim3(256), lds, st, v, w, m, npix, H, W, C / 4,      \
+                         scratch, ppb);                                                                                \
+    else                                                                                                               \
+      hipLaunchKernelGGL((colsum2_partial<MODE, false>), dim3(nb), dim3(256), lds, st, v, w, m, npix, H, W, C / 4,     \
+                         scratch, ppb);                                                                                \
+  } while (0)
+  if (mode == 0) DG_CS2(0);
+  else if (mode == 1) DG_CS2(1);
+  else DG_CS2(2);
+#undef DG_CS2
   HIPCHECK(hipGetLastError());
   hipLaunchKernelGGL(colsum2_final, dim3(C, out1 ? 2 : 1), dim3(256), 0, st, scratch, nb, C, scale, out0, out1);
   HIPCHECK(hipGetLastError());
@@ -147,23 +165,42 @@ __device__ __forceinline__ unsigned hash_u32(unsigned i, unsigned seed) {
   return x;
 }
 
+// FLAT: every view is pixel-contiguous, so pixel q of view t sits at q * t.sX -- 32-bit index arithmetic only.
+template <bool FLAT>
 __global__ void affine_act_kernel(const AffineActArgs a, unsigned drop_thr, float drop_scale) {
   const int C4 = a.C / 4;
   const size_t total = (size_t)a.B * a.H * a.W * C4;
+  const unsigned HW = (unsigned)a.H * (unsigned)a.W;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    size_t q = i;
-    const int c = (int)(q % C4) * 4;
-    q /= C4;
-    const int x = (int)(q % a.W);
-    q /= a.W;
-    const int y = (int)(q % a.H);
-    const int b = (int)(q / a.H);
-    f32x4 v = *reinterpret_cast<const f32x4*>(a.in.p + view_off(a.in, b, y, x) + c);
+    int c, b;
+    long o_in, o_out, o_pre, o_res;
+    if (FLAT) {
+      const unsigned pix = (unsigned)(i / (unsigned)C4);
+      c = (int)((unsigned)i - pix * (unsigned)C4) * 4;
+      b = (int)(pix / HW);
+      o_in = (long)pix * a.in.sX;
+      o_out = (long)pix * a.out.sX;
+      o_pre = (long)pix * a.out_pre.sX;
+      o_res = (long)pix * a.res.sX;
+    } else {
+      size_t q = i;
+      c = (int)(q % C4) * 4;
+      q /= C4;
+      const int x = (int)(q % a.W);
+      q /= a.W;
+      const int y = (int)(q % a.H);
+      b = (int)(q / a.H);
+      o_in = view_off(a.in, b, y, x);
+      o_out = view_off(a.out, b, y, x);
+      o_pre = a.out_pre.p ? view_off(a.out_pre, b, y, x) : 0;
+      o_res = a.res.p ? view_off(a.res, b, y, x) : 0;
+    }
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.in.p + o_in + c);
     const f32x4 sv = *reinterpret_cast<const f32x4*>(a.s + c);
     const f32x4 tv = *reinterpret_cast<const f32x4*>(a.t + c);
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = __fadd_rn(__fmul_rn(v[k], sv[k]), tv[k]);
-    if (a.out_pre.p) *reinterpret_cast<f32x4*>(a.out_pre.p + view_off(a.out_pre, b, y, x) + c) = v;
+    if (a.out_pre.p) *reinterpret_cast<f32x4*>(a.out_pre.p + o_pre + c) = v;
     if (a.film_mul) {
       const f32x4 fm = *reinterpret_cast<const f32x4*>(a.film_mul + (size_t)b * a.film_ld + c);
       const f32x4 fa = *reinterpret_cast<const f32x4*>(a.film_add + (size_t)b * a.film_ld + c);
@@ -180,19 +217,26 @@ __global__ void affine_act_kernel(const AffineActArgs a, unsigned drop_thr, floa
       for (int k = 0; k < 4; ++k) v[k] = (hash_u32(base + k, a.drop_seed) >= drop_thr) ? v[k] * drop_scale : 0.f;
     }
     if (a.res.p) {
-      const f32x4 r = *reinterpret_cast<const f32x4*>(a.res.p + view_off(a.res, b, y, x) + c);
+      const f32x4 r = *reinterpret_cast<const f32x4*>(a.res.p + o_res + c);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] += r[k];
     }
-    *reinterpret_cast<f32x4*>(a.out.p + view_off(a.out, b, y, x) + c) = v;
+    *reinterpret_cast<f32x4*>(a.out.p + o_out + c) = v;
   }
 }
 int dg_affine_act(const AffineActArgs& a, hipStream_t st) {
   if (a.C % 4) { dg_set_error("dg_affine_act: C %% 4 != 0"); return DG_ERR_ARG; }
   const size_t total = (size_t)a.B * a.H * a.W * (a.C / 4);
   const unsigned thr = (unsigned)(a.drop_rate * 4294967296.0);
-  hipLaunchKernelGGL(affine_act_kernel, dim3(t_nblk(total, 8192)), dim3(256), 0, st, a, thr,
-                     1.0f / (1.0f - a.drop_rate));
+  auto is_flat = [&](const TView& t) { return !t.p || (t.sY == (long)a.W * t.sX && t.sB == (long)a.H * t.sY); };
+  const bool flat = is_flat(a.in) && is_flat(a.out) && is_flat(a.out_pre) && is_flat(a.res) &&
+                    (size_t)a.B * a.H * a.W < (1ull << 31);
+  if (flat)
+    hipLaunchKernelGGL(affine_act_kernel<true>, dim3(t_nblk(total, 8192)), dim3(256), 0, st, a, thr,
+                       1.0f / (1.0f - a.drop_rate));
+  else
+    hipLaunchKernelGGL(affine_act_kernel<false>, dim3(t_nblk(total, 8192)), dim3(256), 0, st, a, thr,
+                       1.0f / (1.0f - a.drop_rate));
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
@@ -220,33 +264,52 @@ int dg_bn_bwd_coeffs(const float* sums, const float* mean, const float* rstd, co
   return DG_OK;
 }
 
+template <bool FLAT>
 __global__ void axpby_ch_kernel(TView d, TView xv, TView out, int B, int H, int W, int C4, const float* A,
                                 const float* Bc, const float* Cc) {
   const size_t total = (size_t)B * H * W * C4;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    size_t q = i;
-    const int c = (int)(q % C4) * 4;
-    q /= C4;
-    const int x = (int)(q % W);
-    q /= W;
-    const int y = (int)(q % H);
-    const int b = (int)(q / H);
-    const f32x4 dv = *reinterpret_cast<const f32x4*>(d.p + view_off(d, b, y, x) + c);
-    const f32x4 rv = *reinterpret_cast<const f32x4*>(xv.p + view_off(xv, b, y, x) + c);
+    int c;
+    long o_d, o_x, o_o;
+    if (FLAT) {
+      const unsigned pix = (unsigned)(i / (unsigned)C4);
+      c = (int)((unsigned)i - pix * (unsigned)C4) * 4;
+      o_d = (long)pix * d.sX;
+      o_x = (long)pix * xv.sX;
+      o_o = (long)pix * out.sX;
+    } else {
+      size_t q = i;
+      c = (int)(q % C4) * 4;
+      q /= C4;
+      const int x = (int)(q % W);
+      q /= W;
+      const int y = (int)(q % H);
+      const int b = (int)(q / H);
+      o_d = view_off(d, b, y, x);
+      o_x = view_off(xv, b, y, x);
+      o_o = view_off(out, b, y, x);
+    }
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(d.p + o_d + c);
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(xv.p + o_x + c);
     const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + c);
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bc + c);
     const f32x4 c4 = *reinterpret_cast<const f32x4*>(Cc + c);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = fmaf(a4[k], dv[k], fmaf(b4[k], rv[k], c4[k]));
-    *reinterpret_cast<f32x4*>(out.p + view_off(out, b, y, x) + c) = o;
+    *reinterpret_cast<f32x4*>(out.p + o_o + c) = o;
   }
 }
 int dg_axpby_ch(TView d, TView x, TView out, int B, int H, int W, int C, const float* A, const float* Bc,
                 const float* Cc, hipStream_t st) {
   const size_t total = (size_t)B * H * W * (C / 4);
-  hipLaunchKernelGGL(axpby_ch_kernel, dim3(t_nblk(total, 8192)), dim3(256), 0, st, d, x, out, B, H, W, C / 4, A, Bc,
-                     Cc);
+  auto is_flat = [&](const TView& t) { return t.sY == (long)W * t.sX && t.sB == (long)H * t.sY; };
+  if (is_flat(d) && is_flat(x) && is_flat(out) && (size_t)B * H * W < (1ull << 31))
+    hipLaunchKernelGGL(axpby_ch_kernel<true>, dim3(t_nblk(total, 8192)), dim3(256), 0, st, d, x, out, B, H, W, C / 4, A,
+                       Bc, Cc);
+  else
+    hipLaunchKernelGGL(axpby_ch_kernel<false>, dim3(t_nblk(total, 8192)), dim3(256), 0, st, d, x, out, B, H, W, C / 4,
+                       A, Bc, Cc);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
@@ -332,29 +395,32 @@ int dg_softmax4(const float* logits, float* probs, long P, hipStream_t st) {
 // ---------------------------------------------------------------------------
 // BN over the rows of small matrices (noise MLP), thread = column
 // ---------------------------------------------------------------------------
+// One 256-thread block per column: rows are strided over the threads, sums go through a fixed-order block reduction.
 __global__ void bn_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int C, int ld,
                                    const float* gamma, const float* beta, float eps, float momentum, float corr,
                                    float* mm, float* mv, float* mean, float* rstd, int relu) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float sh4[4];
+  const int c = blockIdx.x;
   float s = 0.f;
-  for (int r = 0; r < R; ++r) s += x[(size_t)r * ld + c];
-  const float mu = s / (float)R;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) s += x[(size_t)r * ld + c];
+  const float mu = t_block_sum(s, sh4) / (float)R;
   float q = 0.f;
-  for (int r = 0; r < R; ++r) {
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
     const float d = x[(size_t)r * ld + c] - mu;
     q = fmaf(d, d, q);
   }
-  const float var = q / (float)R;
+  const float var = t_block_sum(q, sh4) / (float)R;
   const float rs = 1.0f / sqrtf(var + eps);
-  mean[c] = mu;
-  rstd[c] = rs;
-  if (mm) {
-    mm[c] = mm[c] * momentum + mu * (1.0f - momentum);
-    mv[c] = mv[c] * momentum + var * corr * (1.0f - momentum);
+  if (threadIdx.x == 0) {
+    mean[c] = mu;
+    rstd[c] = rs;
+    if (mm) {
+      mm[c] = mm[c] * momentum + mu * (1.0f - momentum);
+      mv[c] = mv[c] * momentum + var * corr * (1.0f - momentum);
+    }
   }
   const float g = gamma[c], bt = beta[c];
-  for (int r = 0; r < R; ++r) {
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
     float v = (x[(size_t)r * ld + c] - mu) * rs * g + bt;
     if (relu) v = fmaxf(v, 0.f);
     y[(size_t)r * ld + c] = v;
@@ -363,8 +429,8 @@ __global__ void bn_rows_fwd_kernel(const float* __restrict__ x, float* __restric
 int dg_bn_rows_fwd(const float* x, float* y, int R, int C, int ld, const float* gamma, const float* beta, float eps,
                    float momentum, float corr, float* moving_mean, float* moving_var, float* mean, float* rstd,
                    int relu, hipStream_t st) {
-  hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, x, y, R, C, ld, gamma, beta, eps, momentum,
-                     corr, moving_mean, moving_var, mean, rstd, relu);
+  hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3(C), dim3(256), 0, st, x, y, R, C, ld, gamma, beta, eps, momentum, corr,
+                     moving_mean, moving_var, mean, rstd, relu);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
@@ -372,20 +438,24 @@ __global__ void bn_rows_bwd_kernel(const float* __restrict__ dy, const float* __
                                    const float* __restrict__ relu_out, float* __restrict__ dx, int R, int C, int ld,
                                    const float* gamma, const float* mean, const float* rstd, float* dgamma,
                                    float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float sh4[4];
+  const int c = blockIdx.x;
   const float mu = mean[c], rs = rstd[c];
   float sd = 0.f, sdx = 0.f;
-  for (int r = 0; r < R; ++r) {
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
     const size_t o = (size_t)r * ld + c;
     const float d = (relu_out && !(relu_out[o] > 0.f)) ? 0.f : dy[o];
     sd += d;
     sdx = fmaf(d, (x[o] - mu) * rs, sdx);
   }
-  dgamma[c] = sdx;
-  dbeta[c] = sd;
+  sd = t_block_sum(sd, sh4);
+  sdx = t_block_sum(sdx, sh4);
+  if (threadIdx.x == 0) {
+    dgamma[c] = sdx;
+    dbeta[c] = sd;
+  }
   const float s = gamma[c] * rs, invR = 1.0f / (float)R;
-  for (int r = 0; r < R; ++r) {
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
     const size_t o = (size_t)r * ld + c;
     const float d = (relu_out && !(relu_out[o] > 0.f)) ? 0.f : dy[o];
     dx[o] = s * (d - sd * invR - (x[o] - mu) * rs * sdx * invR);
@@ -394,8 +464,8 @@ __global__ void bn_rows_bwd_kernel(const float* __restrict__ dy, const float* __
 int dg_bn_rows_bwd(const float* dy, const float* x, const float* relu_out, float* dx, int R, int C, int ld,
                    const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                    hipStream_t st) {
-  hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, dy, x, relu_out, dx, R, C, ld, gamma, mean,
-                     rstd, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3(C), dim3(256), 0, st, dy, x, relu_out, dx, R, C, ld, gamma, mean, rstd,
+                     dgamma, dbeta);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
@@ -413,16 +483,17 @@ int dg_small_gemm(const float* A, const float* Bm, const float* bias, float* Cm,
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
+// C[k][n] = sum_m A[m][k] D[m][n]: one 256-thread block per output element, rows strided over the threads
 __global__ void small_gemm_at_kernel(const float* A, const float* D, float* Cm, int M, int K, int N) {
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= (size_t)K * N) return;
-  const int k = (int)(i / N), n = (int)(i % N);
+  __shared__ float sh4[4];
+  const int k = blockIdx.x / N, n = blockIdx.x % N;
   float acc = 0.f;
-  for (int m = 0; m < M; ++m) acc = fmaf(A[(size_t)m * K + k], D[(size_t)m * N + n], acc);
-  Cm[i] = acc;
+  for (int m = threadIdx.x; m < M; m += blockDim.x) acc = fmaf(A[(size_t)m * K + k], D[(size_t)m * N + n], acc);
+  acc = t_block_sum(acc, sh4);
+  if (threadIdx.x == 0) Cm[blockIdx.x] = acc;
 }
 int dg_small_gemm_at(const float* A, const float* D, float* Cm, int M, int K, int N, hipStream_t st) {
-  hipLaunchKernelGGL(small_gemm_at_kernel, dim3(cdiv((long)K * N, 256)), dim3(256), 0, st, A, D, Cm, M, K, N);
+  hipLaunchKernelGGL(small_gemm_at_kernel, dim3(K * N), dim3(256), 0, st, A, D, Cm, M, K, N);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
@@ -440,14 +511,15 @@ int dg_small_gemm_bt(const float* D, const float* Bm, float* Cm, int M, int K, i
   return DG_OK;
 }
 __global__ void colsum_small_kernel(const float* x, float* out, int R, int C, int ld) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float sh4[4];
+  const int c = blockIdx.x;
   float s = 0.f;
-  for (int r = 0; r < R; ++r) s += x[(size_t)r * ld + c];
-  out[c] = s;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) s += x[(size_t)r * ld + c];
+  s = t_block_sum(s, sh4);
+  if (threadIdx.x == 0) out[c] = s;
 }
 int dg_colsum_small(const float* x, float* out, int R, int C, int ld, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, x, out, R, C, ld);
+  hipLaunchKernelGGL(colsum_small_kernel, dim3(C), dim3(256), 0, st, x, out, R, C, ld);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
