@@ -79,6 +79,7 @@ struct ConvArgs {
   // constants in ONE launch (the 4 taps of a 2x2 / stride-2 transposed convolution): group g uses the packed weights
   // w_group[g] and writes to out.p + out_group_off[g]; `w` is ignored.  0 or 1: a single convolution.
   int groups;
+  int lgx, lgy;   // igemm: logical grid (pixel tiles, channel tiles x groups), filled by the launcher
   const float* w_group[4];
   long out_group_off[4];
 };

@@ -43,7 +43,11 @@ struct Mfma<16> {
   static __device__ __forceinline__ int row(int j, int h) { return 4 * h + j; }
 };
 
-template <int MF, int KS, int CK, int TAPG>
+// PERS: persistent workgroups (the grid is smaller than the item count and every workgroup loops).  The two forms are
+// separate instantiations on purpose: in the looping form the compiler hoists the per-thread staging geometry out of
+// the loop (that is the point), which costs ~36 VGPRs and one resident workgroup per CU -- wrong for launches that
+// run one item per workgroup.
+template <int MF, int KS, int CK, int TAPG, bool PERS>
 __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
   constexpr int NT = MF;
   constexpr int PAD = KS / 2;
@@ -69,28 +73,31 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
   float* ws = smem + PIXT * CKP;   // [TAPG][NT][CKP]
 
   const int tid = threadIdx.x;
-  unsigned long long* dbg = a.dbg ? a.dbg + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 16 : nullptr;
+  unsigned long long* dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;
   if (dbg && tid == 0) {
     dbg[0] = __builtin_amdgcn_s_memtime();
     dbg[6] = __builtin_amdgcn_s_memrealtime();
     dbg[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
   }
   const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + 15) >> 4;
-  // Workgroup -> (pixel tile, channel tile).  Workgroup ids are dealt round-robin over the 8 XCDs (each with its own
-  // L2) in dispatch order.  The channel tiles of one pixel tile read the same halo tile and neighbouring pixel tiles
-  // share two halo columns / rows, so XCD x gets a contiguous eighth of the pixel tiles and walks it with the channel
-  // tile fastest: id = 8 s + x  ->  channel tile s % nNT of pixel tile x (nPix / 8) + s / nNT.
+  // Work item -> (pixel tile, channel tile).  The grid is one-dimensional; a workgroup walks the items id, id + G,
+  // id + 2G ... (G = gridDim.x: every item once when G covers them all, persistent workgroups when the launcher
+  // starts only as many as are resident).  Ids are dealt round-robin over the 8 XCDs (each with its own L2) in
+  // dispatch order.  The channel tiles of one pixel tile read the same halo tile and neighbouring pixel tiles share
+  // two halo columns / rows, so XCD x gets a contiguous eighth of the pixel tiles and walks it with the channel tile
+  // fastest: id = 8 s + x  ->  channel tile s % nNT of pixel tile x (nPix / 8) + s / nNT.
+  const unsigned nNTall = (unsigned)a.lgy, nPix = (unsigned)a.lgx;
+  unsigned id = blockIdx.x;
+  do {
   int t, ntile;
   {
-    const unsigned nNT = gridDim.y, nPix = gridDim.x;
-    const unsigned id = blockIdx.x + blockIdx.y * nPix;
     if ((nPix & 7u) == 0) {
       const unsigned x = id & 7u, sl = id >> 3;
-      ntile = (int)(sl % nNT);
-      t = (int)(x * (nPix >> 3) + sl / nNT);
+      ntile = (int)(sl % nNTall);
+      t = (int)(x * (nPix >> 3) + sl / nNTall);
     } else {
-      t = (int)blockIdx.x;
-      ntile = (int)blockIdx.y;
+      t = (int)(id % nPix);
+      ntile = (int)(id / nPix);
     }
   }
   const int tx0 = (t % tilesX) * 16;
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
   const int b = t / tilesY;
   // grouped launch: the channel-tile index also enumerates the groups (taps of a transposed convolution)
   const int ngrp = a.groups > 1 ? a.groups : 1;
-  const int nNTg = (int)gridDim.y / ngrp;
+  const int nNTg = (int)nNTall / ngrp;
   const int grp = ntile / nNTg;
   ntile -= grp * nNTg;
   const float* wbase = a.groups > 1 ? a.w_group[grp] : a.w;
@@ -321,6 +328,8 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     dbg[5] = __builtin_amdgcn_s_memtime();
     dbg[6] = __builtin_amdgcn_s_memrealtime() - dbg[6];
   }
+  dbg = nullptr;   // stamps describe the first item only
+  } while (PERS && (id += gridDim.x) < nPix * nNTall);
 }
 
 // ---------------------------------------------------------------------------
@@ -370,12 +379,33 @@ static int launch_variant(const ConvArgs& a, hipStream_t st) {
   constexpr size_t lds = lds_k > lds_e ? lds_k : lds_e;
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_kernel<MF, KS, CK, TAPG>),
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_kernel<MF, KS, CK, TAPG, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_kernel<MF, KS, CK, TAPG, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid((unsigned)(cdiv(a.W, 16) * cdiv(a.H, 16) * a.B), (unsigned)(cdiv(a.Cout, MF) * (a.groups > 1 ? a.groups : 1)));
-  hipLaunchKernelGGL((igemm_conv_kernel<MF, KS, CK, TAPG>), grid, dim3(256), lds, st, a);
+  ConvArgs b = a;
+  b.lgx = cdiv(a.W, 16) * cdiv(a.H, 16) * a.B;
+  b.lgy = cdiv(a.Cout, MF) * (a.groups > 1 ? a.groups : 1);
+  long total = (long)b.lgx * b.lgy;
+  long G = total;
+  {
+    // Persistent workgroups (two per CU, each walking total / G items, when that divides evenly) compute the
+    // per-thread staging geometry once per workgroup instead of once per item, but hold ~36 more VGPRs, i.e. two
+    // resident workgroups per CU instead of three.  Measured per layer on one device (tools/cmp_persist.py): the
+    // 5x5 critic layers gain 3-5 %, the 3x3 layers lose 0-6 %, so only KS = 5 runs persistent by default.
+    // Uneven splits (e.g. 752 workgroups for 8192 items) lose 15 %, hence the divisibility condition.
+    // DEPGAN_IGEMM_PERSIST=<workgroups per CU> forces a setting for all shapes (0 = never) for A/B measurements.
+    const char* e = getenv("DEPGAN_IGEMM_PERSIST");
+    const int per_cu = e ? atoi(e) : (KS == 5 ? 2 : 0);
+    const long cap = 256L * per_cu;
+    if (per_cu > 0 && total >= 2 * cap && total % cap == 0) G = cap;
+  }
+  if (G < total)
+    hipLaunchKernelGGL((igemm_conv_kernel<MF, KS, CK, TAPG, true>), dim3((unsigned)G), dim3(256), lds, st, b);
+  else
+    hipLaunchKernelGGL((igemm_conv_kernel<MF, KS, CK, TAPG, false>), dim3((unsigned)G), dim3(256), lds, st, b);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }

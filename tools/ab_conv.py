@@ -14,7 +14,7 @@ for (B,H,W,ci,co,k) in shapes:
     res = {v: [] for v in variants}
     for rnd in range(6):
         for v in variants:
-            os.environ["DEPGAN_IGEMM_VAR"] = str(v)
+            os.environ[os.environ.get("AB_KEY", "DEPGAN_IGEMM_VAR")] = str(v)
             lib.depgan_op_conv2d_stamps(P(x),P(w),P(out),B,H,W,ci,co,k,None,3,None); torch.cuda.synchronize()
             t = time.perf_counter(); lib.depgan_op_conv2d_stamps(P(x),P(w),P(out),B,H,W,ci,co,k,None,30,None); torch.cuda.synchronize()
             res[v].append((time.perf_counter() - t) / 30 * 1e6)
