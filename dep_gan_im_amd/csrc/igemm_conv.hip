@@ -48,7 +48,7 @@ struct Mfma<16> {
 // the loop (that is the point), which costs ~36 VGPRs and one resident workgroup per CU -- wrong for launches that
 // run one item per workgroup.
 template <int MF, int KS, int CK, int TAPG, bool PERS>
-__global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_kernel(const ConvArgs a) {
   constexpr int NT = MF;
   constexpr int PAD = KS / 2;
   constexpr int TW = 16 + KS - 1;
@@ -391,16 +391,21 @@ static int launch_variant(const ConvArgs& a, hipStream_t st) {
   long total = (long)b.lgx * b.lgy;
   long G = total;
   {
-    // Persistent workgroups (two per CU, each walking total / G items, when that divides evenly) compute the
-    // per-thread staging geometry once per workgroup instead of once per item, but hold ~36 more VGPRs, i.e. two
-    // resident workgroups per CU instead of three.  Measured per layer on one device (tools/cmp_persist.py): the
-    // 5x5 critic layers gain 3-5 %, the 3x3 layers lose 0-6 %, so only KS = 5 runs persistent by default.
-    // Uneven splits (e.g. 752 workgroups for 8192 items) lose 15 %, hence the divisibility condition.
+    // Persistent workgroups: as many as are resident per CU (3 by registers, fewer where the LDS tile is large), each
+    // walking ~total / G items.  The per-thread staging geometry and address arithmetic (about 550 instructions per
+    // item) is then computed once per workgroup.  Every workgroup of the grid MUST be resident: one that has to wait
+    // for a slot runs its whole share after the others have finished (752 workgroups at 2 resident per CU: +20 %).
+    // Measured per layer on one device (tools/cmp_persist.py): 3x3 layers +1..4 %, 5x5 layers +3..5 %, 1x1 -9 %.
     // DEPGAN_IGEMM_PERSIST=<workgroups per CU> forces a setting for all shapes (0 = never) for A/B measurements.
     const char* e = getenv("DEPGAN_IGEMM_PERSIST");
-    const int per_cu = e ? atoi(e) : (KS == 5 ? 2 : 0);
+    // the 3x3 persistent instantiation is compiled for 3 resident workgroups per CU; the others take what their
+    // registers allow (2)
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > (KS == 3 ? 3 : 2)) per_cu = (KS == 3 ? 3 : 2);
+    if (KS == 1) per_cu = 0;   // K is one chunk: nothing to amortise, measured -0.17 ms per step when persistent
+    if (e) per_cu = atoi(e) < per_cu ? atoi(e) : per_cu;
     const long cap = 256L * per_cu;
-    if (per_cu > 0 && total >= 2 * cap && total % cap == 0) G = cap;
+    if (per_cu > 0 && total >= 4 * cap) G = cap;
   }
   if (G < total)
     hipLaunchKernelGGL((igemm_conv_kernel<MF, KS, CK, TAPG, true>), dim3((unsigned)G), dim3(256), lds, st, b);
