@@ -98,3 +98,27 @@ def test_maxpool(lib):
     torch.cuda.synchronize()
     ref = F.max_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("case", [(16, 128, 128, 32, 64, 3), (12, 96, 112, 16, 16, 5), (8, 72, 136, 96, 32, 3)])
+def test_persistent_conv_grid_matches_one_item_per_workgroup(lib, case, monkeypatch):
+    """The persistent form of the conv kernel (workgroups looping over items, staging geometry hoisted) must give
+    the same bits as the one-item-per-workgroup form, on interior and border tiles (ragged sizes) alike."""
+    from dep_gan_im_amd import _lib
+    B, H, W, ci, co, k = case
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(ci + co + k)
+    x = torch.from_numpy(rng.standard_normal((B, H, W, ci)).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rng.standard_normal((k, k, ci, co)) / np.sqrt(k * k * ci)).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.standard_normal(co).astype(np.float32)).to(dev)
+    outs = []
+    for per_cu in ("0", "1", "2"):
+        monkeypatch.setenv("DEPGAN_IGEMM_PERSIST", per_cu)      # read by the launcher at every launch
+        out = torch.full((B, H, W, co), float("nan"), device=dev)
+        _lib.check(lib.depgan_op_conv2d(P(x), P(w), P(b), P(out), B, H, W, ci, co, k, 1, 1, None))
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[2])
+    ref = _ref_conv(x[:2].cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), True)
+    assert rel(outs[1][:2], ref) < TOL
