@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdepgan.so")
+LIB_PATH = os.environ.get("DEPGAN_LIB") or os.path.join(HERE, "libdepgan.so")   # DEPGAN_LIB: A/B another build
 
 EXPORTS = [
     "depgan_last_error", "depgan_create", "depgan_destroy", "depgan_set_stream", "depgan_param_count",

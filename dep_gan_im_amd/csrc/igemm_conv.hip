@@ -353,30 +353,49 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_ker
       fm4 = *reinterpret_cast<const f32x4*>(e.film_mul + (long)b * e.film_ld + co);
       fa4 = *reinterpret_cast<const f32x4*>(e.film_add + (long)b * e.film_ld + co);
     }
-    // per-lane byte offsets inside a pass (pixel pl0 of the pass, channel co), one per view
-    const unsigned lo_out = 4u * (unsigned)(pl0 * (int)a.out.sX + co);
-    const unsigned lo_pre = has_pre ? 4u * (unsigned)(pl0 * (int)e.out_pre.sX + co) : 0u;
-    const unsigned lo_res = has_res ? 4u * (unsigned)(pl0 * (int)e.res.sX + co) : 0u;
-    const unsigned lo_msk = has_msk ? 4u * (unsigned)(pl0 * (int)e.mask.sX + co) : 0u;
-    // uniform bases of pass 0: pixel (oyw, tx0) of sample b
-    const char* ub_out = reinterpret_cast<const char*>(a.out.p + out_goff + view_off(a.out, b, oyw, tx0));
-    const char* ub_pre = has_pre ? reinterpret_cast<const char*>(e.out_pre.p + view_off(e.out_pre, b, oyw, tx0)) : nullptr;
-    const char* ub_res = has_res ? reinterpret_cast<const char*>(e.res.p + view_off(e.res, b, oyw, tx0)) : nullptr;
-    const char* ub_msk = has_msk ? reinterpret_cast<const char*>(e.mask.p + view_off(e.mask, b, oyw, tx0)) : nullptr;
+    // Buffer addressing: per view one resource descriptor (SGPRs) at pixel (oyw, tx0) of sample b, a per-lane byte
+    // offset computed once (pixel pl0 of the pass, channel co) and a scalar byte offset per pass -- the eight passes
+    // issue no address arithmetic on the vector ALU at all.
+    auto mk = [&](const float* p) {
+      // the descriptor must be wave-uniform: the pointer depends on the wave index
+      const unsigned long long u = (unsigned long long)p;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7FFFFFFF, 0x00020000);
+    };
+    const int lo_out = 4 * (pl0 * (int)a.out.sX + co);
+    const int lo_pre = has_pre ? 4 * (pl0 * (int)e.out_pre.sX + co) : 0;
+    const int lo_res = has_res ? 4 * (pl0 * (int)e.res.sX + co) : 0;
+    const int lo_msk = has_msk ? 4 * (pl0 * (int)e.mask.sX + co) : 0;
+    const __amdgpu_buffer_rsrc_t r_out = mk(a.out.p + out_goff + view_off(a.out, b, oyw, tx0));
+    const __amdgpu_buffer_rsrc_t r_pre = mk(has_pre ? e.out_pre.p + view_off(e.out_pre, b, oyw, tx0) : a.out.p);
+    const __amdgpu_buffer_rsrc_t r_res = mk(has_res ? e.res.p + view_off(e.res, b, oyw, tx0) : a.out.p);
+    const __amdgpu_buffer_rsrc_t r_msk = mk(has_msk ? e.mask.p + view_off(e.mask, b, oyw, tx0) : a.out.p);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
+      const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+      return __builtin_bit_cast(f32x4, t);
+    };
+    auto st = [&](const __amdgpu_buffer_rsrc_t& r, int voff, int soff, f32x4 v) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, voff, soff, 0);
+    };
+    const int sY_out = 4 * (int)a.out.sY, sX_out = 4 * (int)a.out.sX;
+    const int sY_pre = 4 * (int)e.out_pre.sY, sX_pre = 4 * (int)e.out_pre.sX;
+    const int sY_res = 4 * (int)e.res.sY, sX_res = 4 * (int)e.res.sX;
+    const int sY_msk = 4 * (int)e.mask.sY, sX_msk = 4 * (int)e.mask.sX;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       // pass p covers pixels (py, px0 .. px0 + PPP) of the wave's 4 x 16 block
       const int py = (p * PPP) >> 4, px0 = (p * PPP) & 15;
-      if (!full && (oyw + py >= a.H || tx0 + px0 + pl0 >= a.W)) continue;
-      const long d_out = 4 * ((long)py * a.out.sY + (long)px0 * a.out.sX);   // scalar
+      const bool ok = full || (oyw + py < a.H && tx0 + px0 + pl0 < a.W);
       f32x4 v = *reinterpret_cast<const f32x4*>(es + (p * PPP + pl0) * CP + c4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         v[k] += bias4[k];
         if (affine) v[k] = __fadd_rn(__fmul_rn(v[k], sc4[k]), sh4[k]);
       }
-      if (has_pre)
-        *reinterpret_cast<f32x4*>(const_cast<char*>(ub_pre) + 4 * ((long)py * e.out_pre.sY + (long)px0 * e.out_pre.sX) + lo_pre) = v;
+      if (has_pre) {
+        if (ok) st(r_pre, lo_pre, py * sY_pre + px0 * sX_pre, v);
+      }
       if (film) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = film_preact(v[k], fm4[k], fa4[k]);
@@ -386,22 +405,25 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_ker
         for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
       }
       if (has_res) {
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(ub_res + 4 * ((long)py * e.res.sY + (long)px0 * e.res.sX) + lo_res);
+        f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+        if (ok) rr = ld(r_res, lo_res, py * sY_res + px0 * sX_res);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] += rr[k];
       }
       if (has_msk) {
-        const f32x4 mm = *reinterpret_cast<const f32x4*>(ub_msk + 4 * ((long)py * e.mask.sY + (long)px0 * e.mask.sX) + lo_msk);
+        f32x4 mm = {1.f, 1.f, 1.f, 1.f};
+        if (ok) mm = ld(r_msk, lo_msk, py * sY_msk + px0 * sX_msk);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = (mm[k] > 0.f) ? v[k] : 0.f;
       }
-      f32x4* o = reinterpret_cast<f32x4*>(const_cast<char*>(ub_out) + d_out + lo_out);
+      const int so = py * sY_out + px0 * sX_out;
       if (accum) {
-        const f32x4 old = *o;
+        f32x4 old = {0.f, 0.f, 0.f, 0.f};
+        if (ok) old = ld(r_out, lo_out, so);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] += old[k];
       }
-      *o = v;
+      if (ok) st(r_out, lo_out, so, v);
     }
   }
   if (dbg && tid == 0) {
