@@ -41,7 +41,7 @@ struct MfmaW<16> {
 };
 
 // ---------------------------------------------------------------------------
-// Staging: LDS-DMA (global_load_lds_dwordx4), double-buffered, one workgroup per CU.
+// Staging: LDS-DMA (buffer_load_dwordx4 ... lds), double-buffered, one workgroup per CU.
 //
 // Nine (or 25) accumulator tiles leave no registers to hold a tile in flight, and with register staging the
 // load and MFMA phases of co-resident workgroups ran in lockstep, so the matrix pipe idled during every staging phase
@@ -49,15 +49,10 @@ struct MfmaW<16> {
 // into the second of two LDS buffers while the MFMAs of the current tile run: two raw barriers and one counted vmcnt
 // per tile, accumulators in AGPRs, no spills (113-117 TFLOP/s on the 3x3 layers).
 // The LDS image is the [pixel][MF] one of the header, which is lane-linear per wave-instruction (64 lanes x 16 B =
-// 64*16/(4 MF) pixels) as the DMA requires; out-of-image pixels and channel tails read a 16-byte zero constant instead
-// (the per-lane SOURCE address is free), so no lane is ever masked and every wave issues the same number of pieces.
+// 64*16/(4 MF) pixels) as the DMA requires; out-of-image pixels and channel tails carry an out-of-range buffer offset
+// instead (the per-lane SOURCE address is free and the hardware returns zeros for it), so no lane is ever masked and
+// every wave issues the same number of pieces.
 // ---------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) float dg_zero16[4] = {0.f, 0.f, 0.f, 0.f};
-
-#define DG_GLDS16(src, dst)                                                                               \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                   \
-                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-
 template <int MF, int KS, int TPW, int TH>
 struct WDmaCfg {
   static constexpr int TW = 16 + KS - 1, THH = TH + KS - 1, PIXT = THH * TW, V = MF / 4;
@@ -65,7 +60,7 @@ struct WDmaCfg {
   static constexpr int NXP = (XTOT + 255) / 256, NDP = DTOT / 256;   // DMA instructions per wave per tile
   static constexpr int XBUF = NXP * 256 * 4, DBUF = DTOT * 4, BUF = XBUF + DBUF;   // floats
   static constexpr size_t LDS_TILES = (size_t)2 * BUF * sizeof(float);
-  static constexpr size_t LDS_RED = (size_t)4 * MF * MF * sizeof(float);
+  static constexpr size_t LDS_RED = (size_t)TPW * 4 * MF * MF * sizeof(float);   // every tap's 4 wave partials
   static constexpr size_t LDS_BYTES = LDS_TILES > LDS_RED ? LDS_TILES : LDS_RED;
   static_assert(DTOT % 256 == 0, "dy tile must be whole wave-instructions");
 };
@@ -118,104 +113,158 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < MfmaW<MF>::NREG; ++j) acc[t][j] = 0.f;
 
-  // per-thread piece geometry, fixed for the whole kernel
-  int xofs[NXP], xyx[NXP];
+  // ---- tile staging: buffer-addressed LDS-DMA ----
+  // One descriptor per operand; a piece's address is descriptor base + per-lane byte offset (fixed for the whole
+  // kernel) + a scalar tile offset, so an interior tile costs no vector ALU work at all.  The x descriptor's base is
+  // moved back by the halo, which keeps the per-lane offsets non-negative; lanes that must read zeros (halo outside
+  // the image, channels past Cin / Cout, padding pieces) carry an offset beyond num_records, for which the hardware
+  // returns 0.
+  const float* const xorg = a.x.p + ci0 - PAD * ((long)a.x.sY + (long)a.x.sX);
+  const float* const dorg = a.dy.p + co0;
+  constexpr int SENT = (int)0x80000000;
+  int xvo[NXP], xyx[NXP];
 #pragma unroll
   for (int i = 0; i < NXP; ++i) {
     const int q = tid + i * 256;
     const int pix = q / V, part = q & (V - 1);
     const int ly = pix / TW, lx = pix - ly * TW;
-    xofs[i] = (ly - PAD) * (int)a.x.sY + (lx - PAD) * (int)a.x.sX + part * 4;
-    xyx[i] = (q < XTOT) ? ((ly << 8) | lx) : -1;       // -1: padding piece behind the halo tile
+    const bool ok = q < XTOT && (ci0 + part * 4) < a.Cin;      // q >= XTOT: padding piece behind the halo tile
+    xvo[i] = ok ? 4 * (ly * (int)a.x.sY + lx * (int)a.x.sX + part * 4) : SENT;
+    xyx[i] = (ly << 8) | lx;
   }
-  const int dpart = (tid & (V - 1)) * 4;
-  const bool cxok = (ci0 + dpart) < a.Cin, cdok = (co0 + dpart) < a.Cout;
-  const float* zsrc = dg_zero16;
+  constexpr int DROWS = 256 / V / 16;                           // dy rows covered by one wave-instruction round
+  const int dly = (tid / V) >> 4, dlx = (tid / V) & 15;
+  const int dvo = ((co0 + (tid & (V - 1)) * 4) < a.Cout)
+                      ? 4 * (dly * (int)a.dy.sY + dlx * (int)a.dy.sX + (tid & (V - 1)) * 4)
+                      : SENT;
+  const int dstep = 4 * DROWS * (int)a.dy.sY;
+  const int wbase = __builtin_amdgcn_readfirstlane(wv * 256);   // this wave's float offset inside a 256-piece round
 
-  auto issue = [&](int tile, int buf) {
-    int t = tile;
-    const int tx0 = (t % tilesX) * 16;
+  // tile coordinates of the next tile to stage, advanced incrementally (no divisions inside the loop)
+  int ntx, nty, nb;
+  {
+    int t = t0;
+    ntx = t % tilesX;
     t /= tilesX;
-    const int ty0 = (t % tilesY) * TH;
-    const int b = t / tilesY;
-    const float* xb = a.x.p + ((long)b * a.x.sB + (long)ty0 * a.x.sY + (long)tx0 * a.x.sX + ci0);
-    const float* db = a.dy.p + ((long)b * a.dy.sB + (long)ty0 * a.dy.sY + (long)tx0 * a.dy.sX + co0);
-    const bool interior = ty0 >= PAD && ty0 + TH + PAD <= a.H && tx0 >= PAD && tx0 + 16 + PAD <= a.W;
-    float* xs = smem + buf * BUF;
-    float* ds = xs + XBUF;
-#pragma unroll
-    for (int i = 0; i < NXP; ++i) {
-      bool ok = cxok && xyx[i] >= 0;
-      if (!interior) {
-        const int iy = ty0 + (xyx[i] >> 8) - PAD, ix = tx0 + (xyx[i] & 255) - PAD;
-        ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      }
-      const float* src = ok ? (xb + xofs[i]) : zsrc;
-      DG_GLDS16(src, xs + (tid + i * 256) * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < NDP; ++i) {
-      const int q = tid + i * 256;
-      const int pix = q / V;
-      const int ly = pix >> 4, lx = pix & 15;
-      const bool ok = cdok && (interior || (ty0 + ly < a.H && tx0 + lx < a.W));
-      const float* src = ok ? (db + (ly * (int)a.dy.sY + lx * (int)a.dy.sX + dpart)) : zsrc;
-      DG_GLDS16(src, ds + q * 4);
-    }
-  };
+    nty = t % tilesY;
+    nb = t / tilesY;
+  }
 
   const int fragB = ((wv * (TH / 4)) * 16 + h) * MF + r;   // float offsets inside a buffer's D / X images
   const int fragX = ((wv * (TH / 4) + (TPW == NTAPS ? 0 : tg)) * TW + h) * MF + r;
 
-  if (t0 < t1) issue(t0, 0);
-  for (int tile = t0; tile < t1; ++tile) {
+  // The loop starts one tile early: that first pass only stages tile t0 (into buffer 0) and computes nothing, so
+  // the staging code exists once.
+  for (int tile = t0 - 1; tile < t1; ++tile) {
     const int buf = (tile - t0) & 1;
     // every wave has finished the MFMA loop of tile-1 (its LDS reads were consumed by those MFMAs), so the other
     // buffer may be overwritten
     __builtin_amdgcn_s_barrier();
     if (tile + 1 < t1) {
-      issue(tile + 1, buf ^ 1);
+      const int tx0 = ntx * 16, ty0 = nty * TH;
+      const int xso = 4 * (nb * (int)a.x.sB + ty0 * (int)a.x.sY + tx0 * (int)a.x.sX);
+      const int dso = 4 * (nb * (int)a.dy.sB + ty0 * (int)a.dy.sY + tx0 * (int)a.dy.sX);
+      const bool interior = ty0 >= PAD && ty0 + TH + PAD <= a.H && tx0 >= PAD && tx0 + 16 + PAD <= a.W;
+      float* xs = smem + (buf ^ 1) * BUF + wbase;
+      float* ds = xs + XBUF;
+      auto mkrsrc = [](const float* p) {
+        const unsigned long long u = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7FFFFFFF,
+                                                 0x00020000);
+      };
+      const __amdgpu_buffer_rsrc_t rx = mkrsrc(xorg), rd = mkrsrc(dorg);
+      if (interior) {
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+          // (a plain int local: with a type-dependent argument such as xvo[i] hipcc drops the host-side
+          // instantiation of the kernel without a diagnostic)
+          const int vo = xvo[i];
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + i * 1024), 16,
+                                                   vo, xso, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NDP; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(ds + i * 1024), 16,
+                                                   dvo, dso + i * dstep, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+          const int iy = ty0 + (xyx[i] >> 8) - PAD, ix = tx0 + (xyx[i] & 255) - PAD;
+          const int vo = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? xvo[i] : SENT;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + i * 1024), 16,
+                                                   vo, xso, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NDP; ++i) {
+          const int vo = ((ty0 + dly + i * DROWS) < a.H && (tx0 + dlx) < a.W) ? dvo : SENT;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(ds + i * 1024), 16,
+                                                   vo, dso + i * dstep, 0, 0);
+        }
+      }
+      if (++ntx == tilesX) {
+        ntx = 0;
+        if (++nty == tilesY) {
+          nty = 0;
+          ++nb;
+        }
+      }
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");   // this wave's pieces of `tile` have landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                                      // ... and so have everybody else's
-    float afr[2][TPW], bfr[2];
+    if (tile < t0) continue;
     if (COUNTED) {
       // Fragment reads as inline asm with counted waits: for compiler-visible ds_reads hipcc puts
       // s_waitcnt lgkmcnt(0) in front of every other MFMA group, which also waits for the reads of the NEXT k-step
       // issued just before, and with one wave per SIMD nothing hides that LDS latency.  LDS reads retire in order,
       // so leaving the NREAD newest outstanding means the previous k-step's have arrived; sched_barriers pin
       // read -> wait -> MFMA.
+      // Two consecutive k-steps of one lane are 256 bytes apart in both images (2 pixels of 32 channels, or 4 of
+      // 16), which is the unit of ds_read2st64_b32: one LDS instruction fetches the fragment values of a PAIR of
+      // k-steps.  Its offsets count 256-byte units, so the sub-256 remainder of a tap's offset is carried by one of
+      // four pre-offset base registers.
       const unsigned bbase =
           (unsigned)(size_t)(__attribute__((address_space(3))) float*)(smem + buf * BUF + XBUF + fragB);
       const unsigned xbase = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(smem + buf * BUF + fragX);
-      auto load_frag = [&](int kk, float* av, float& bv) {
+      const unsigned xb[4] = {xbase, xbase + 64u, xbase + 128u, xbase + 192u};
+      static_assert(KSTEPS % 2 == 0 && (16 / KM) % 2 == 0, "k-steps are paired inside a pixel row");
+      auto load_pair = [&](int kp, f32x2* av, f32x2& bv) {
         constexpr int SPR = 16 / KM;
+        const int kk = 2 * kp;
         const int pyo = kk / SPR, pxo = (kk % SPR) * KM;
-        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bv) : "v"(bbase), "n"(4 * (pyo * 16 + pxo) * MF));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3"
+                     : "=v"(bv)
+                     : "v"(bbase), "n"((4 * (pyo * 16 + pxo) * MF) / 256), "n"((4 * (pyo * 16 + pxo) * MF) / 256 + 1));
 #pragma unroll
         for (int tl = 0; tl < TPW; ++tl) {
           const int ty = (TPW == NTAPS) ? (tl / KS) : 0;   // row offset already in fragX for row groups
           const int tx = (TPW == NTAPS) ? (tl % KS) : tl;
-          asm volatile("ds_read_b32 %0, %1 offset:%2"
+          const int off = 4 * ((pyo + ty) * TW + pxo + tx) * MF;
+          asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3"
                        : "=v"(av[tl])
-                       : "v"(xbase), "n"(4 * ((pyo + ty) * TW + pxo + tx) * MF));
+                       : "v"(xb[(off % 256) / 64]), "n"(off / 256), "n"(off / 256 + 1));
         }
       };
-      load_frag(0, afr[0], bfr[0]);
+      f32x2 afr[2][TPW], bfr[2];
+      load_pair(0, afr[0], bfr[0]);
 #pragma unroll
-      for (int kk = 0; kk < KSTEPS; ++kk) {
-        if (kk + 1 < KSTEPS) load_frag(kk + 1, afr[(kk + 1) & 1], bfr[(kk + 1) & 1]);
+      for (int kp = 0; kp < KSTEPS / 2; ++kp) {
+        if (kp + 1 < KSTEPS / 2) load_pair(kp + 1, afr[(kp + 1) & 1], bfr[(kp + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        if (kk + 1 < KSTEPS) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(COUNTED ? NREAD : 0) : "memory");
+        if (kp + 1 < KSTEPS / 2) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(COUNTED ? NREAD : 0) : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[kk & 1][tl], bfr[kk & 1], acc[tl]);
+        for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[kp & 1][tl].x, bfr[kp & 1].x, acc[tl]);
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[kp & 1][tl].y, bfr[kp & 1].y, acc[tl]);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
+      float afr[2][TPW], bfr[2];
       const float* bbase = smem + buf * BUF + XBUF + fragB;
       const float* xbase = smem + buf * BUF + fragX;
       auto load_frag = [&](int kk, float* av, float& bv) {
@@ -241,27 +290,30 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     }
   }
 
-  // ---- sum the 4 waves through LDS and write one slab per workgroup (as wgrad_kernel) ----
-  float* red = smem;  // [4][MF*MF]
+  // ---- sum the 4 waves through LDS and write one slab per workgroup: all taps in one pass (two barriers) ----
+  float* red = smem;  // [TPW][4][MF*MF]
   const size_t slab = (size_t)NTAPS * a.Cin * a.Cout;
   float* pout = a.part + (size_t)chunk * slab;
+  __syncthreads();    // every wave is done with the tile buffers
 #pragma unroll
-  for (int tl = 0; tl < TPW; ++tl) {
-    __syncthreads();
+  for (int tl = 0; tl < TPW; ++tl)
 #pragma unroll
-    for (int j = 0; j < MfmaW<MF>::NREG; ++j) red[wv * MF * MF + MfmaW<MF>::row(j, h) * MF + r] = acc[tl][j];
-    __syncthreads();
+    for (int j = 0; j < MfmaW<MF>::NREG; ++j)
+      red[(tl * 4 + wv) * MF * MF + MfmaW<MF>::row(j, h) * MF + r] = acc[tl][j];
+  __syncthreads();
+  for (int q = tid; q < TPW * MF * MF; q += 256) {
+    const int tl = q / (MF * MF), e = q % (MF * MF);
+    const float* rt = red + tl * 4 * MF * MF;
+    const float sum = (rt[e] + rt[MF * MF + e]) + (rt[2 * MF * MF + e] + rt[3 * MF * MF + e]);
     const int tap = tg * TPW + tl;
-    for (int e = tid; e < MF * MF; e += 256) {
-      const float sum = (red[e] + red[MF * MF + e]) + (red[2 * MF * MF + e] + red[3 * MF * MF + e]);
-      const int ci = ci0 + e / MF, co = co0 + e % MF;
-      if (ci < a.Cin && co < a.Cout) pout[((size_t)tap * a.Cin + ci) * a.Cout + co] = sum;
-    }
+    const int ci = ci0 + e / MF, co = co0 + e % MF;
+    if (ci < a.Cin && co < a.Cout) pout[((size_t)tap * a.Cin + ci) * a.Cout + co] = sum;
   }
 }
 
 struct WVar {
   int MF, KS, TPW, TH;
+  size_t lds;
 };
 
 static void pick_variant(int KS, int Cin, int Cout, WVar* v) {
@@ -273,6 +325,13 @@ static void pick_variant(int KS, int Cin, int Cout, WVar* v) {
     v->TPW = 5;
     v->TH = 8;
   }
+  v->lds = 0;
+  if (KS == 3 && v->MF == 32) v->lds = WDmaCfg<32, 3, 9, 16>::LDS_BYTES;
+  if (KS == 3 && v->MF == 16) v->lds = WDmaCfg<16, 3, 9, 16>::LDS_BYTES;
+  if (KS == 5 && v->MF == 32) v->lds = WDmaCfg<32, 5, 5, 8>::LDS_BYTES;
+  if (KS == 5 && v->MF == 16) v->lds = WDmaCfg<16, 5, 25, 16>::LDS_BYTES;
+  if (KS == 1 && v->MF == 32) v->lds = WDmaCfg<32, 1, 1, 16>::LDS_BYTES;
+  if (KS == 1 && v->MF == 16) v->lds = WDmaCfg<16, 1, 1, 16>::LDS_BYTES;
 }
 
 static void chunking(const WVar& v, int B, int H, int W, int Cin, int Cout, int* nTiles, int* tilesPerChunk,
@@ -280,7 +339,11 @@ static void chunking(const WVar& v, int B, int H, int W, int Cin, int Cout, int*
   const int tilesX = cdiv(W, 16), tilesY = cdiv(H, v.TH);
   *nTiles = B * tilesX * tilesY;
   *gridY = cdiv(Cin, v.MF) * cdiv(Cout, v.MF) * (v.KS * v.KS / v.TPW);
-  int want = 512 / *gridY;   // one workgroup per CU is resident (two where the tile buffers are small): two rounds
+  // ONE round of workgroups: as many as are resident at once (one per CU, two where two sets of tile buffers fit the
+  // CU's LDS).  A workgroup's prologue (cold first tile) and epilogue (slab) are not overlapped with anything on its
+  // CU, and every further round costs them again (measured: 1024 / 512 / 256 workgroups -> 386 / 372 / 358 us).
+  const int per_cu = (v.lds && 2 * v.lds <= (size_t)160 * 1024) ? 2 : 1;
+  int want = 256 * per_cu / *gridY;
   if (want < 1) want = 1;
   if (want > *nTiles) want = *nTiles;
   *tilesPerChunk = cdiv(*nTiles, want);
@@ -317,6 +380,13 @@ int dg_wgrad(int KS, const WgradArgs& a_in, int* nchunks_out, hipStream_t st) {
       (a.dy.sY % 4) || (a.dy.sB % 4) || (((uintptr_t)a.x.p) & 15) || (((uintptr_t)a.dy.p) & 15)) {
     dg_set_error("dg_wgrad: channels and strides must be multiples of 4 floats (Cin=%d Cout=%d)", a.Cin, a.Cout);
     return DG_ERR_ARG;
+  }
+  // the staging DMA addresses both operands with 32-bit byte offsets from one buffer descriptor each
+  const long long lim = 0x7FFFFFFFll - (1ll << 20);
+  if ((long long)a.B * a.x.sB * 4 + ((long long)a.x.sY + a.x.sX) * 4 * KS >= lim || (long long)a.B * a.dy.sB * 4 >= lim) {
+    dg_set_error("dg_wgrad: operand spans 2 GiB or more (B=%d, batch strides %ld / %ld floats)", a.B, (long)a.x.sB,
+                 (long)a.dy.sB);
+    return DG_ERR_UNSUPPORTED;
   }
   WVar v;
   pick_variant(KS, a.Cin, a.Cout, &v);
