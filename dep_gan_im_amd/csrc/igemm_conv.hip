@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_ker
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = Mfma<MF>::run(av[q & 1][mt][j], bv[q & 1][j], acc[mt]);
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = Mfma<MF>::run(bv[q & 1][j], av[q & 1][mt][j], acc[mt]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -310,21 +310,27 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_ker
   if (dbg && tid == 0) dbg[4] = __builtin_amdgcn_s_memtime();
   // ---- epilogue ----
   // The CU retires only about one vector-memory wave-instruction per ~100 cycles here, so the
-  // accumulator layout (lane = channel, 16 pixels per lane => 32 dword stores per lane) made the
-  // store tail as long as the MFMA phase.  Transpose each wave's 64 x NT tile through LDS and
-  // emit 16-byte accesses: 8 lanes x 16 B cover one pixel's 32 channels (one full 128-B line).
+  // store tail is as long as the MFMA phase unless every instruction covers whole lines.  Each wave's 64 x NT tile
+  // goes through LDS and is emitted as 16-byte accesses: 8 lanes x 16 B cover one pixel's 32 channels (one full
+  // 128-B line).  (Storing the quads straight from the accumulators -- 32 lines of 32 bytes per instruction -- was
+  // measured 3 % slower than this.)
   __syncthreads();  // every wave is done with its fragment reads; the tile region is free
   constexpr int CP = NT + 4;
   float* es = smem + wv * (64 * CP);
+  // The MFMAs take the WEIGHT fragment as their first operand, so the accumulators hold the transposed tile
+  // D[channel][pixel]: lane (r, h) owns pixel r of each pixel tile and its registers 4g .. 4g+3 are four consecutive
+  // channels (8g + 4h + 0..3 of the 32x32 tile, 4h + 0..3 of the 16x16 one) -> one 16-byte LDS write per quad
+  // (rows of CP = NT + 4 floats: 8 consecutive lanes hit 8 different 16-byte bank groups).
+  constexpr int NQ = (MF == 32) ? 4 : 1, CSTEP = (MF == 32) ? 8 : 4;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int j = 0; j < Mfma<MF>::NREG; ++j) {
-      const int pl = (MF == 32) ? ((2 * mt + (j >> 3)) * 16 + ((j & 3) + 8 * ((j >> 2) & 1) + 4 * h))
-                                : (mt * 16 + 4 * h + j);
-      es[pl * CP + r] = acc[mt][j];
+    for (int g = 0; g < NQ; ++g) {
+      f32x4 q4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q4[k] = acc[mt][4 * g + k];
+      *reinterpret_cast<f32x4*>(es + (MF * mt + r) * CP + CSTEP * g + 4 * h) = q4;
     }
-  }
   // On a SIMD nothing that is issued overlaps with fp32 MFMAs, so the epilogue is written for
   // instruction count: every operand test is a scalar branch on a kernel argument, and every access is
   // (uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset computed once) so that the loads and stores take the
