@@ -10,3 +10,4 @@ from .models import Dis_C2D_FCN1, Gen_UNet2D  # noqa: F401
 from .trainers import Trainers, build_trainers  # noqa: F401
 from .engine import Engine  # noqa: F401
 from . import evaluate  # noqa: F401,E402
+from . import data, nifti  # noqa: F401,E402

@@ -18,6 +18,7 @@ EXPORTS = [
     "depgan_profile_reset", "depgan_profile_dump", "depgan_op_conv2d", "depgan_op_conv2d_bwd_data", "depgan_op_conv2d_wgrad",
     "depgan_op_maxpool", "depgan_op_conv2d_stamps", "depgan_uresnet_grads", "depgan_uresnet_step",
     "depgan_uresnet_eval", "depgan_profile_read_bytes", "depgan_g_eval_multi", "depgan_eval_accumulate", "depgan_eval_counts",
+    "depgan_data_prep_scratch_floats", "depgan_data_prep_subject",
 ]
 
 
@@ -85,6 +86,9 @@ def load():
     lib.depgan_op_conv2d_wgrad.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp]
     lib.depgan_eval_accumulate.argtypes = [vp, vp, vp, C.c_long, C.c_float, vp]
     lib.depgan_eval_counts.argtypes = [vp, C.c_int] + [vp] * 7 + [C.c_long, C.c_float, C.POINTER(C.c_longlong), vp]
+    lib.depgan_data_prep_scratch_floats.argtypes = [C.c_int] * 3
+    lib.depgan_data_prep_scratch_floats.restype = C.c_size_t
+    lib.depgan_data_prep_subject.argtypes = [vp] * 7 + [C.c_int] * 4 + [vp] * 4
     lib.depgan_op_maxpool.argtypes = [vp, vp] + [C.c_int] * 4 + [vp]
     lib.depgan_op_conv2d_stamps.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, vp]
     lib.depgan_uresnet_grads.argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint, fp]

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdepgan.so")
 SOURCES = ["igemm_conv.hip", "wgrad.hip", "direct.hip", "ops.hip", "noise.hip", "train_ops.hip", "model.hip",
-           "uresnet.hip"]
+           "uresnet.hip", "data.hip"]
 ARCH = "gfx950"
 
 

@@ -131,6 +131,19 @@ int depgan_eval_counts(const float* x_dev, int nicg, const float* pred_dev, cons
                        const float* prob2_dev, long npix, float thr, long long out_host[DEPGAN_EVAL_NCOUNT],
                        void* stream);
 
+/* ---- data step in front of the path (DEP-GAN_PROB_IM_twoCritics_training_4fold.py "GT": 93-118 load_data /
+ * data_prep, 124-146 map_image_to_intensity_range, 667-723 masking / clamping / channel concat) ----
+ * One subject: volumes are device fp32 arrays in NIfTI file order (x fastest: element (x,y,z) at x + X*(y + Y*z)),
+ * already cast to float32 as data_prep does.  Writes the training slices x_out (Z, X, Y, nicg) and y2_out (Z, X, Y, 1):
+ *   prob_1 = p1*icv1 [*(1 - sl1)] clamped at 0;  flair_1 = f1*icv1 [*(1 - sl1)] mapped to [0,1] by the subject's min /
+ *   max (percentile 0);  prob_2 = p2*icv2 [*(1 - sl2)] clamped at 0.  sl1 / sl2 may be NULL (no stroke-lesion mask:
+ *   GT:691, 699 skip it when the file is missing); f1 may be NULL when nicg = 1.  Bit-identical to the NumPy statements.
+ *   scratch: depgan_data_prep_scratch_floats(X, Y, Z) device floats (needed for nicg = 2).  Enqueued on `stream`. */
+size_t depgan_data_prep_scratch_floats(int X, int Y, int Z);
+int depgan_data_prep_subject(const float* p1_dev, const float* f1_dev, const float* icv1_dev, const float* sl1_dev,
+                             const float* p2_dev, const float* icv2_dev, const float* sl2_dev, int X, int Y, int Z,
+                             int nicg, float* x_out_dev, float* y2_out_dev, float* scratch_dev, void* stream);
+
 /* ---- single operators (unit-test surface; device pointers) ---- */
 /* path: 0 auto, 1 MFMA implicit GEMM, 2 direct */
 int depgan_op_conv2d(const float* in, const float* w_hwio, const float* bias, float* out, int B, int H, int W,
