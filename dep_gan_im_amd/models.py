@@ -147,6 +147,17 @@ class _Model:
     save = save_weights   # netG.save(...) GT:892 (architecture is code here; the file holds the weights)
 
     def load_weights(self, path):
+        """`.npz` written by save_weights, or a Keras 2.x HDF5 file (`model.save` / `save_weights`: GT:892, GE:383)
+        when h5py is installed -- the names and layouts here are the Keras ones, so that import is a lookup."""
+        if str(path).lower().endswith((".h5", ".hdf5")):
+            try:
+                import h5py
+            except ImportError as e:
+                raise ImportError("reading Keras HDF5 weights needs h5py (not installed); convert the file to .npz "
+                                  "with weights_from_keras_h5 on a machine that has it") from e
+            with h5py.File(path, "r") as f:
+                self.set_weights(weights_from_keras_h5(f, [n for n, _, _ in self._named_table()]))
+            return
         with np.load(path) as f:
             self.set_weights({k: f[k] for k in f.files})
 
@@ -162,6 +173,40 @@ class _Model:
             print_fn("%-44s %-22s %10d" % (n, str(tuple(s)), k))
         print_fn("=" * 78)
         print_fn("Total params: %d\nTrainable params: %d\nNon-trainable params: %d" % (tot, tr_tot, tot - tr_tot))
+
+
+def weights_from_keras_h5(f, names):
+    """Maps a Keras 2.x HDF5 weight file onto this package's weight names ("<layer>/<weight>").
+
+    f: an open h5py.File (anything indexable the same way).  `model.save` files keep the layers under the group
+    "model_weights", `save_weights` files at the root; each layer group holds its tensors at
+    "<layer>/<weight>:0" (a nested group named after the layer again).  Layers the file does not have, or extra ones,
+    are an error: a silent partial load would pass every shape check and train from a half-initialised model."""
+    g = f["model_weights"] if "model_weights" in f else f
+    out, missing = OrderedDict(), []
+    for n in names:
+        layer, w = n.split("/", 1)
+        ds = None
+        if layer in g:
+            lg = g[layer]
+            for key in ("%s/%s:0" % (layer, w), "%s:0" % w, "%s/%s" % (layer, w), w):
+                node, ok = lg, True
+                for part in key.split("/"):
+                    if hasattr(node, "keys") and part in node:
+                        node = node[part]
+                    else:
+                        ok = False
+                        break
+                if ok and not hasattr(node, "keys"):
+                    ds = node
+                    break
+        if ds is None:
+            missing.append(n)
+        else:
+            out[n] = np.asarray(ds[()] if hasattr(ds, "shape") and not isinstance(ds, np.ndarray) else ds, np.float32)
+    if missing:
+        raise KeyError("Keras HDF5 file lacks %d of %d weights, e.g. %s" % (len(missing), len(names), missing[:3]))
+    return out
 
 
 def _gen_static_table(nicg, fm, nc_out):

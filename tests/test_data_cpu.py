@@ -105,3 +105,26 @@ def test_file_lists(tmp_path):
     (tmp_path / "icv_2tp_fold3.txt").write_text("/d/i2_0.nii.gz\n")
     with pytest.raises(ValueError):
         dgdata.training_file_lists(str(tmp_path), 3)
+
+
+def test_keras_h5_name_mapping():
+    """The HDF5 importer is a lookup by Keras layer / weight names (h5py itself is absent here: a nested dict stands in
+    for the open file, which is all the mapping touches)."""
+    from dep_gan_im_amd import Gen_UNet2D
+    from dep_gan_im_amd.models import weights_from_keras_h5
+    g = Gen_UNet2D((64, 64, 1), (32, 1), 32, 1, seed=3)
+    names = [n for n, _, _ in g._named_table()]
+    want = g.get_weights_dict()
+    layers = {}
+    for n in names:
+        layer, w = n.split("/", 1)
+        layers.setdefault(layer, {layer: {}})[layer][w + ":0"] = want[n]
+    got = weights_from_keras_h5({"model_weights": layers}, names)           # model.save layout (GT:892)
+    assert list(got) == names and all(np.array_equal(got[n], want[n]) for n in names)
+    got = weights_from_keras_h5(layers, names)                              # save_weights layout
+    assert all(np.array_equal(got[n], want[n]) for n in names)
+    del layers["conv2d_gen_0"]
+    with pytest.raises(KeyError):
+        weights_from_keras_h5(layers, names)
+    with pytest.raises(ImportError):
+        g.load_weights("/nonexistent/netG.h5")                               # h5py is not installed in this image
