@@ -83,6 +83,12 @@ struct ConvArgs {
   int lgx, lgy;   // igemm: logical grid (pixel tiles, channel tiles x groups), filled by the launcher
   const float* w_group[4];
   long out_group_off[4];
+  // igemm only: gathered K.  cpt > 0 splits the Cin axis into consecutive runs of cpt channel chunks; run r reads its
+  // channels at in.p + in_run_off[r] (floats) instead of contiguously after run r-1 -- the backward-data of the
+  // 2x2 / stride-2 transposed convolution as ONE 1x1 convolution over the four strided pixel grids of its upstream
+  // gradient (K = 4 Cout).  The run length cpt * CK must divide into whole chunks (no channel tail inside a run).
+  int cpt;
+  long in_run_off[4];
 };
 
 struct WgradArgs {

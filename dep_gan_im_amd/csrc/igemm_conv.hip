@@ -149,11 +149,19 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_ker
 
   const bool interior = ty0 >= PAD && ty0 + 16 + PAD <= a.H && tx0 >= PAD && tx0 + 16 + PAD <= a.W;
   const char* halo0 = reinterpret_cast<const char*>(inb + ((long)(ty0 - PAD) * a.in.sY + (long)(tx0 - PAD) * a.in.sX));
+  // first input channel (float offset from the pixel) of channel chunk cc; see ConvArgs::cpt for the gathered form
+  auto coff = [&](int cc) -> long {
+    if (a.cpt > 0) {
+      const int run = cc / a.cpt;
+      return a.in_run_off[run] + (long)(cc - run * a.cpt) * CK;
+    }
+    return (long)cc * CK;
+  };
   auto prefetch = [&](int s) {
     const int cc = s / NG, tg = s - cc * NG;
     if (PERS) {
       if (tg == 0) {
-        const char* src = halo0 + 4 * cc * CK;   // only dereferenced through in-image offsets
+        const char* src = halo0 + 4 * coff(cc);   // only dereferenced through in-image offsets
         if (interior && (cc + 1) * CK <= a.Cin) {
 #pragma unroll
           for (int i = 0; i < XFULL; ++i) xr[i] = *reinterpret_cast<const f32x4*>(src + xgb[i]);
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_ker
           const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
           const int c = cc * CK + part * 4;
           if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin)
-            v = *reinterpret_cast<const f32x4*>(inb + (long)iy * a.in.sY + (long)ix * a.in.sX + c);
+            v = *reinterpret_cast<const f32x4*>(inb + (long)iy * a.in.sY + (long)ix * a.in.sX + coff(cc) + part * 4);
         }
         xr[i] = v;
       }
@@ -536,6 +544,15 @@ int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
       misaligned(a.ep.out_pre) || (a.Cout % 4) || (a.ep.film_mul && (a.ep.film_ld % 4))) {
     dg_set_error("dg_conv_igemm: views must be 16-byte aligned (pointers, strides and Cout multiples of 4 floats)");
     return DG_ERR_ARG;
+  }
+  if (a.cpt > 0) {
+    const int run = a.cpt * pl.CK;
+    bool bad = a.groups > 1 || (a.Cin % run) != 0 || a.Cin / run > 4;
+    for (int r = 0; !bad && r < a.Cin / run; ++r) bad = (a.in_run_off[r] % 4) != 0;
+    if (bad) {
+      dg_set_error("dg_conv_igemm: gathered K needs Cin = runs (<= 4) x cpt x %d channels and 16-byte run offsets", pl.CK);
+      return DG_ERR_ARG;
+    }
   }
   switch (pl.variant) {
     case 0: return launch_variant<32, 3, 16, 9>(a, st);

@@ -59,6 +59,10 @@ struct GLayer {
   ConvPlan pf, pb;
   float* wpf[4] = {nullptr, nullptr, nullptr, nullptr};
   float* wpb[4] = {nullptr, nullptr, nullptr, nullptr};
+  // deconv backward-data as ONE 1x1 convolution over the four strided grids of the upstream gradient (K = 4 Cout):
+  // the four per-tap panels interleaved per channel tile; null when the channel counts do not allow it
+  ConvPlan pbf;
+  float* wpb_all = nullptr;
   // FiLM
   int col_mul = -1, col_add = -1;
   // tensors
@@ -188,6 +192,7 @@ int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS);
 void zero_ep(Epilogue* e);
 TView view_offset(TView v, long samples);
 TView strided2(TView v, int di, int dj);
+int deconv_bwd_data(depgan_ctx* c, GLayer& L, TView dsrc, int n);
 // column sums of dy over its first B samples, delivered with the weight gradient: out = scale * sum, raw = sum
 struct ColSum {
   int B;

@@ -115,6 +115,32 @@ int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
   return dg_conv_direct(KS, a, c->st);
 }
 
+int deconv_bwd_data(depgan_ctx* c, GLayer& L, TView dsrc, int n) {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  zero_ep(&a.ep);
+  a.out = L.din;
+  a.B = n; a.H = L.H; a.W = L.W; a.Cout = L.Cin;
+  a.ep.mask = L.in_mask;
+  if (L.wpb_all) {
+    // dIn[p] = sum_t W_t^T dOut[2p + t]: one 1x1 convolution whose K axis gathers the four strided pixel grids
+    a.in = strided2(dsrc, 0, 0);
+    a.Cin = 4 * L.Cout;
+    a.cpt = L.Cout / L.pb.CK;
+    for (int t = 0; t < 4; ++t) a.in_run_off[t] = (long)(t / 2) * dsrc.sY + (long)(t % 2) * dsrc.sX;
+    a.w = L.wpb_all;
+    return conv_launch(c, L.pbf, a, 1);
+  }
+  a.Cin = L.Cout;
+  for (int t = 0; t < 4; ++t) {
+    a.in = strided2(dsrc, t / 2, t % 2);
+    a.w = L.wpb[t];
+    a.ep.accumulate = (t > 0);
+    DGCHECK(conv_launch(c, L.pb, a, 1));
+  }
+  return DG_OK;
+}
+
 void zero_ep(Epilogue* e) {
   memset(e, 0, sizeof(*e));
   e->out_pre = e->res = e->mask = null_view();
@@ -403,6 +429,10 @@ static int build_generator(depgan_ctx* c) {
         DGCHECK(dmalloc(c, &L.wpf[t], L.pf.packedFloats));
         DGCHECK(dmalloc(c, &L.wpb[t], L.pb.packedFloats));
       }
+      L.pbf = dg_plan_conv(1, 4 * L.Cout, L.Cin);
+      if (L.pb.variant >= 0 && L.pbf.variant == L.pb.variant && (L.Cout % L.pb.CK) == 0 &&
+          L.pbf.packedFloats == 4 * L.pb.packedFloats)
+        DGCHECK(dmalloc(c, &L.wpb_all, L.pbf.packedFloats));
       Cat& ct = cats[e.aux];
       L.out = ct.fwd.slice(0);    // (2H, 2W) grid, first Cout channels
       L.dout = ct.grad.slice(0);
@@ -547,6 +577,12 @@ int refresh_generator(depgan_ctx* c) {
         const float* src = L.Wt + (size_t)t * L.Cout * L.Cin;  // (kh,kw,Cout,Cin)
         DGCHECK(dg_pack_weights(L.pf, src, L.Cin, L.Cout, 1, 0, 0, nullptr, L.wpf[t], c->st));
         DGCHECK(dg_pack_weights(L.pb, src, L.Cin, L.Cout, 1, 1, 0, ks, L.wpb[t], c->st));
+        if (L.wpb_all) {
+          // panel of channel tile nt, tap t -> [nt][t][chunk][n][k]: the K axis of the fused launch is (tap, channel)
+          const size_t blk = (size_t)L.pb.nCC * L.pb.NT * L.pb.CK * sizeof(float);
+          HIPCHECK(hipMemcpy2DAsync(reinterpret_cast<char*>(L.wpb_all) + t * blk, 4 * blk, L.wpb[t], blk, blk,
+                                    (size_t)L.pb.nNT, hipMemcpyDeviceToDevice, c->st));
+        }
       }
     }
   }
@@ -689,18 +725,7 @@ int g_backward(depgan_ctx* c, const float* x, const float* z, int n) {
         DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 4 * L.Cin, L.Cout, 1, L.Cin, L.b, L.mean, L.rstd, L.dbeta, L.dgamma,
                                  c->st));
       }
-      for (int t = 0; t < 4; ++t) {
-        ConvArgs a;
-        memset(&a, 0, sizeof(a));
-        zero_ep(&a.ep);
-        a.in = strided2(L.dout, t / 2, t % 2);
-        a.out = L.din;
-        a.w = L.wpb[t];
-        a.B = n; a.H = L.H; a.W = L.W; a.Cin = L.Cout; a.Cout = L.Cin;
-        a.ep.mask = L.in_mask;
-        a.ep.accumulate = (t > 0);
-        DGCHECK(conv_launch(c, L.pb, a, 1));
-      }
+      DGCHECK(deconv_bwd_data(c, L, L.dout, n));
     }
   }
   ProfScope ps(c, 2, 0.0);

@@ -314,18 +314,7 @@ static int u_backward(depgan_ctx* c, const float* x, const float* z, int n) {
         DGCHECK(wgrad_full(c, 1, L.in, strided2(draw, t / 2, t % 2), n, L.H, L.W, L.Cin, L.Cout, nullptr, L.dW + o,
                            nullptr, 0, 1));
       }
-      for (int t = 0; t < 4; ++t) {
-        ConvArgs a;
-        memset(&a, 0, sizeof(a));
-        zero_ep(&a.ep);
-        a.in = strided2(draw, t / 2, t % 2);
-        a.out = L.din;
-        a.w = L.wpb[t];
-        a.B = n; a.H = L.H; a.W = L.W; a.Cin = L.Cout; a.Cout = L.Cin;
-        a.ep.mask = L.in_mask;
-        a.ep.accumulate = (t > 0);
-        DGCHECK(conv_launch(c, L.pb, a, 1));
-      }
+      DGCHECK(deconv_bwd_data(c, L, draw, n));
     }
   }
   ProfScope ps(c, 2, 0.0);
