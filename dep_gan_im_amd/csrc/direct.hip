@@ -129,6 +129,198 @@ static int launch_direct(const ConvArgs& a, hipStream_t st) {
   return DG_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Cout = 1 (backward-data of dis_0a onto the image, the dD/dx of GT:543): one output channel leaves nothing to
+// amortise an input value over except neighbouring pixels, and the generic kernel above spends two LDS reads per FMA.
+// Here a thread owns 4 consecutive pixels of a 32 x 32 tile: per (channel, tap row) it reads 8 inputs (two 16-byte
+// LDS reads) and KS weights for 4 KS FMAs -- 4 LDS instructions per 20 FMAs for 5x5.
+// ---------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(const ConvArgs a) {
+  constexpr int PAD = KS / 2;
+  constexpr int TWX = 32 + KS - 1, TWY = 32 + KS - 1;
+  constexpr int RS = 40;            // LDS row stride (floats): 16-byte aligned rows, 8 floats of slack past column 35
+  constexpr int CIK = 8;            // input channels per LDS chunk
+  constexpr int WS = 8;             // padded tap-row length
+  static_assert(TWX <= RS && KS <= WS, "tile row must fit the LDS row");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                          // [CIK][TWY][RS]
+  float* ws = smem + CIK * TWY * RS;         // [CIK][KS][WS]
+
+  const int tid = threadIdx.x;
+  const int tilesX = (a.W + 31) >> 5, tilesY = (a.H + 31) >> 5;
+  int t = blockIdx.x;
+  const int tx0 = (t % tilesX) * 32;
+  t /= tilesX;
+  const int ty0 = (t % tilesY) * 32;
+  const int b = t / tilesY;
+  const int qx = (tid & 7) * 4, py = tid >> 3;      // this thread's 4 pixels: row py, columns qx .. qx+3
+  const float* inb = a.in.p + (long)b * a.in.sB;
+  const bool in4 = !(a.Cin % 4) && !(a.in.sX % 4) && !(a.in.sY % 4) && !(a.in.sB % 4) && !(((uintptr_t)a.in.p) & 15);
+
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < a.Cin; c0 += CIK) {
+    const int cik = min(CIK, a.Cin - c0);
+    __syncthreads();
+    if (in4 && cik == CIK) {
+      for (int q = tid; q < TWX * TWY * 2; q += 256) {
+        const int pix = q >> 1, part = (q & 1) * 4;
+        const int ly = pix / TWX, lx = pix - ly * TWX;
+        const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+          v = *reinterpret_cast<const f32x4*>(inb + (long)iy * a.in.sY + (long)ix * a.in.sX + c0 + part);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xs[((part + k) * TWY + ly) * RS + lx] = v[k];
+      }
+    } else {
+      for (int q = tid; q < TWX * TWY * cik; q += 256) {
+        const int pix = q / cik, c = q - pix * cik;
+        const int ly = pix / TWX, lx = pix - ly * TWX;
+        const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
+        float v = 0.f;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = inb[(long)iy * a.in.sY + (long)ix * a.in.sX + c0 + c];
+        xs[(c * TWY + ly) * RS + lx] = v;
+      }
+    }
+    for (int q = tid; q < cik * KS * WS; q += 256) {
+      const int tx = q % WS, ty = (q / WS) % KS, c = q / (WS * KS);
+      float v = 0.f;
+      if (tx < KS) {
+        const int tap = ty * KS + tx;
+        const int ts = a.flip ? (KS * KS - 1 - tap) : tap;
+        v = a.w[(long)ts * a.wsT + (long)(c0 + c) * a.wsI];
+      }
+      ws[(c * KS + ty) * WS + tx] = v;
+    }
+    __syncthreads();
+    for (int c = 0; c < cik; ++c) {
+#pragma unroll
+      for (int ty = 0; ty < KS; ++ty) {
+        const float* row = xs + (c * TWY + py + ty) * RS + qx;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(row);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + 4);
+        const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        const float* wr = ws + (c * KS + ty) * WS;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr);
+        const float w4 = (KS > 4) ? wr[4] : 0.f;
+        const float wv[5] = {w0[0], w0[1], w0[2], w0[3], w4};
+        // tap-major, then channel, then tap row, then tap column: a fixed order, so results are run-to-run identical
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv[j + tx], wv[tx], acc[j]);
+      }
+    }
+  }
+  const EpiChan ch = epi_load_chan(a.ep, b, 0, a.Cout);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = ty0 + py, ox = tx0 + qx + j;
+    if (oy < a.H && ox < a.W) epi_store(a, ch, b, oy, ox, 0, acc[j]);
+  }
+}
+
+template <int KS>
+static int launch_cout1(const ConvArgs& a, hipStream_t st) {
+  constexpr int TW = 32 + KS - 1;
+  constexpr size_t lds = (size_t)(8 * TW * 40 + 8 * KS * 8) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_kernel<KS>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(cdiv(a.W, 32) * cdiv(a.H, 32) * a.B));
+  hipLaunchKernelGGL((conv_cout1_kernel<KS>), grid, dim3(256), lds, st, a);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Cin = 1 or 2 (gen_0 GT:398, dis_0a GT:319 and its gradient-penalty u-forward): the output write is the only HBM
+// traffic that matters and the work is KS^2 Cin FMAs per output value.  Thread = 4 consecutive pixels x 4 consecutive
+// output channels; per (channel, tap row) it reads 8 inputs (two 16-byte LDS reads) and KS weight quads for 16 KS
+// FMAs (7 LDS instructions per 80 FMAs for 5x5, where the generic kernel needs 25).  Block = 16 pixels wide,
+// 256 / (Cout / 4) / 4 rows high; Cout / 4 threads cover one pixel group's channels, so a wave's 16-byte stores fill
+// whole lines.
+// ---------------------------------------------------------------------------
+template <int KS, int G>   // G = Cout / 4 channel groups: 4 (Cout 16) or 8 (Cout 32)
+__global__ __launch_bounds__(256) void conv_cin12_kernel(const ConvArgs a) {
+  constexpr int PAD = KS / 2;
+  constexpr int ROWS = 256 / G / 4;          // tile height
+  constexpr int TWX = 16 + KS - 1, TWY = ROWS + KS - 1;
+  constexpr int RS = 24;                     // LDS row stride (floats)
+  constexpr int CT = 4 * G;
+  static_assert(TWX + 3 <= RS, "row with read slack must fit");
+  __shared__ __attribute__((aligned(16))) float xs[2 * TWY * RS];
+  __shared__ __attribute__((aligned(16))) float ws[2 * KS * KS * CT];
+
+  const int tid = threadIdx.x;
+  const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + ROWS - 1) / ROWS;
+  int t = blockIdx.x;
+  const int tx0 = (t % tilesX) * 16;
+  t /= tilesX;
+  const int ty0 = (t % tilesY) * ROWS;
+  const int b = t / tilesY;
+  const int g = tid % G, pg = tid / G;       // channel group, pixel group
+  const int qx = (pg & 3) * 4, py = pg >> 2;
+  const float* inb = a.in.p + (long)b * a.in.sB;
+
+  for (int q = tid; q < a.Cin * TWY * RS; q += 256) {
+    const int lx = q % RS, ly = (q / RS) % TWY, c = q / (RS * TWY);
+    const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
+    float v = 0.f;
+    if (lx < TWX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = inb[(long)iy * a.in.sY + (long)ix * a.in.sX + c];
+    xs[q] = v;
+  }
+  for (int q = tid; q < a.Cin * KS * KS * CT; q += 256) {
+    const int n = q % CT, tap = (q / CT) % (KS * KS), c = q / (CT * KS * KS);
+    const int ts = a.flip ? (KS * KS - 1 - tap) : tap;
+    ws[q] = (n < a.Cout) ? a.w[(long)ts * a.wsT + (long)c * a.wsI + (long)n * a.wsO] : 0.f;
+  }
+  __syncthreads();
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // channel, tap row, tap column: the generic kernel's order is tap-major; either is a fixed order
+  for (int c = 0; c < a.Cin; ++c) {
+#pragma unroll
+    for (int ty = 0; ty < KS; ++ty) {
+      const float* row = xs + (c * TWY + py + ty) * RS + qx;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(row);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + 4);
+      const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+      for (int tx = 0; tx < KS; ++tx) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws + ((c * KS + ty) * KS + tx) * CT + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[j][k] = fmaf(xv[j + tx], w4[k], acc[j][k]);
+      }
+    }
+  }
+  const int co = 4 * g;
+  if (co < a.Cout) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int oy = ty0 + py, ox = tx0 + qx + j;
+      if (oy < a.H && ox < a.W) epi_store4(a, b, oy, ox, co, acc[j]);
+    }
+  }
+}
+
+template <int KS, int G>
+static int launch_cin12(const ConvArgs& a, hipStream_t st) {
+  constexpr int ROWS = 256 / G / 4;
+  dim3 grid((unsigned)(cdiv(a.W, 16) * cdiv(a.H, ROWS) * a.B));
+  hipLaunchKernelGGL((conv_cin12_kernel<KS, G>), grid, dim3(256), 0, st, a);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
 int dg_conv_direct(int KS, const ConvArgs& a_in, hipStream_t st) {
   ConvArgs a = a_in;
   auto aligned = [](const TView& v) {
@@ -137,13 +329,17 @@ int dg_conv_direct(int KS, const ConvArgs& a_in, hipStream_t st) {
   a.vec4 = (a.Cout % 4 == 0) && aligned(a.out) && aligned(a.ep.res) && aligned(a.ep.mask) && aligned(a.ep.out_pre) &&
            (!a.ep.film_mul || a.ep.film_ld % 4 == 0);
   const int sel = (a.Cout == 1) ? 0 : ((a.Cout <= 16) ? 1 : 2);
+  if (a.Cin <= 2 && a.vec4 && (a.Cout == 16 || a.Cout == 32) && (KS == 3 || KS == 5)) {
+    if (KS == 3) return (a.Cout == 16) ? launch_cin12<3, 4>(a, st) : launch_cin12<3, 8>(a, st);
+    return (a.Cout == 16) ? launch_cin12<5, 4>(a, st) : launch_cin12<5, 8>(a, st);
+  }
   if (KS == 3) {
-    if (sel == 0) return launch_direct<3, 1, 1>(a, st);
+    if (sel == 0) return (a.Cin >= 4) ? launch_cout1<3>(a, st) : launch_direct<3, 1, 1>(a, st);
     if (sel == 1) return launch_direct<3, 4, 4>(a, st);
     return launch_direct<3, 4, 8>(a, st);
   }
   if (KS == 5) {
-    if (sel == 0) return launch_direct<5, 1, 1>(a, st);
+    if (sel == 0) return (a.Cin >= 4) ? launch_cout1<5>(a, st) : launch_direct<5, 1, 1>(a, st);
     if (sel == 1) return launch_direct<5, 4, 4>(a, st);
     return launch_direct<5, 4, 8>(a, st);
   }

@@ -404,3 +404,11 @@ def test_bench_size_properties_batch32_256(lib):
     assert srel(combine_generator_sums(sums), ev) < 1e-4
     # and the values are sane against the oracle on the first two samples (forward only, seconds on the CPU)
     np.testing.assert_allclose(attr[:2], O.g_predict(PG, x[:2], z[:2]), rtol=1e-3, atol=1e-4)
+
+
+def test_other_generator_widths_fail_loudly(lib):
+    """The reference fixes first_fm_G = 32 (GT:354 call site); the noise-MLP kernels are sized for it.  Another width is
+    refused at creation instead of running a wrong model."""
+    from dep_gan_im_amd import DepganError, Engine
+    with pytest.raises(DepganError, match="first_fm"):
+        Engine(2, 64, 64, 1, first_fm=16)

@@ -33,6 +33,10 @@ CONV_CASES = [  # B,H,W,Cin,Cout,k,path
     (2, 32, 32, 16, 16, 5, 1), (2, 32, 32, 16, 32, 5, 1), (2, 32, 32, 32, 32, 5, 1), (2, 17, 33, 32, 16, 5, 1),
     (2, 32, 32, 128, 128, 1, 1), (2, 32, 32, 48, 48, 3, 1), (1, 16, 16, 256, 256, 3, 1),
     (2, 32, 32, 1, 32, 3, 2), (2, 32, 32, 2, 32, 3, 2), (2, 30, 18, 1, 16, 5, 2), (2, 32, 32, 16, 1, 5, 2),
+    # single output channel (dD/dx): the 4-pixels-per-thread kernel, ragged tiles, channel tails, both kernel sizes
+    (2, 45, 70, 16, 1, 5, 2), (2, 33, 31, 8, 1, 3, 2), (1, 40, 40, 6, 1, 5, 2), (1, 20, 36, 12, 1, 3, 2),
+    # one or two input channels: the 4-pixels x 4-channels-per-thread kernel
+    (1, 37, 50, 2, 16, 5, 2), (1, 20, 20, 1, 32, 5, 2), (2, 19, 33, 2, 16, 3, 2),
 ]
 
 
