@@ -97,6 +97,10 @@ struct WgradArgs {
   float* part;  // [nchunks][ntaps][Cin][Cout] partial sums
   int B, H, W, Cin, Cout;
   int nTiles, tilesPerChunk;
+  // MFMA kernel only: when non-null, the column sums of dy over the samples b < colB (bias / BN-beta gradients) ride
+  // along: the workgroups of input-channel tile 0 / tap group 0 write one partial row per chunk, [nchunks][Cout]
+  float* colpart;
+  int colB;
 };
 
 #define DG_OK 0

@@ -171,24 +171,38 @@ int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, in
   a.Cin = Cin;
   a.Cout = Cout;
   a.nTiles = a.tilesPerChunk = 0;
+  a.colpart = nullptr;
+  a.colB = 0;
   int nch = 0;
   const double fl = 2.0 * N * H * W * (double)Cin * Cout * KS * KS;
   char lb[56];
   snprintf(lb, sizeof(lb), "wgrad k%d b%d %dx%d %d->%d", KS, N, H, W, Cin, Cout);
-  if (cs) {
-    // Column sums of dy (bias / BN-beta gradients).  Riding them in the MFMA weight-gradient kernel was tried and
-    // dropped: its 3x3 variant holds 9 accumulator tiles and sits at the 256-VGPR limit of 2 workgroups per CU,
-    // the 4 extra live registers cost 10 % of its rate -- more than this separate streaming pass.
+  const bool mfma = Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 8;
+  // Column sums of dy (bias / BN-beta gradients) ride in the MFMA weight-gradient kernel, whose B fragments are the
+  // dy values anyway (2 FMAs per 18 MFMAs in one workgroup column; with the register-staged kernel of earlier in the
+  // round the same idea cost 10 % -- it sat at the VGPR limit of two workgroups per CU).  The edge-layer kernels keep
+  // the separate streaming pass.
+  if (cs && !mfma) {
     ProfScope ps(c, 2, 0.0, "colsum");
     DGCHECK(dg_colsum(dy, cs->B, H, W, Cout, cs->scale, cs->out, cs->raw, 0, c->scratch, c->st));
   }
-  if (Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 8) {
+  if (mfma) {
     if (dg_wgrad_part_floats(KS, N, H, W, Cin, Cout) > c->partFloats) {
       dg_set_error("wgrad slab workspace too small");
       return DG_ERR_ARG;
     }
-    ProfScope ps(c, 1, fl, lb);
-    DGCHECK(dg_wgrad(KS, a, &nch, c->st));
+    if (cs) {
+      a.colpart = c->scratch;
+      a.colB = cs->B;
+    }
+    {
+      ProfScope ps(c, 1, fl, lb);
+      DGCHECK(dg_wgrad(KS, a, &nch, c->st));
+    }
+    if (cs) {
+      ProfScope ps(c, 2, 0.0, "colsum");
+      DGCHECK(dg_colsum_finish(c->scratch, nch, Cout, cs->scale, cs->out, cs->raw, 0, c->st));
+    }
   } else {
     if (dg_wgrad_small_part_floats(KS, N, H, W, Cin, Cout) > c->partFloats) {
       dg_set_error("wgrad slab workspace too small");
@@ -1315,6 +1329,8 @@ int depgan_op_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, in
   a.part = part;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.nTiles = a.tilesPerChunk = 0;
+  a.colpart = nullptr;
+  a.colB = 0;
   int nch = 0;
   int rc = big ? dg_wgrad(KS, a, &nch, st) : dg_wgrad_small(KS, a, &nch, st);
   if (rc == DG_OK) rc = dg_wgrad_reduce(part, nch, KS * KS, Cin, Cout, nullptr, dw, nullptr, 0, 0, st);

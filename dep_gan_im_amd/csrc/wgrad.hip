@@ -140,6 +140,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
   const int dstep = 4 * DROWS * (int)a.dy.sY;
   const int wbase = __builtin_amdgcn_readfirstlane(wv * 256);   // this wave's float offset inside a 256-piece round
 
+  // Column sums of dy ride along where asked for: the B fragment of a k-step IS dy[pixel][co], every pixel of a tile
+  // is some lane's fragment exactly once per tap group, so summing the fragments per lane (2 FMAs per pair of
+  // k-steps next to 18 MFMAs) and folding lanes and waves at the end gives the tile's column sums.  Only the
+  // workgroups of input-channel tile 0 / tap group 0 carry a non-zero multiplier.
+  const bool do_cs = a.colpart != nullptr && ci0 == 0 && tg == 0;
+  float cs0 = 0.f, cs1 = 0.f;
+  int bq[2] = {0, 0};          // sample index of the tile held by each LDS buffer
   // tile coordinates of the next tile to stage, advanced incrementally (no divisions inside the loop)
   int ntx, nty, nb;
   {
@@ -167,6 +174,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
       const bool interior = ty0 >= PAD && ty0 + TH + PAD <= a.H && tx0 >= PAD && tx0 + 16 + PAD <= a.W;
       float* xs = smem + (buf ^ 1) * BUF + wbase;
       float* ds = xs + XBUF;
+      bq[buf ^ 1] = nb;
       auto mkrsrc = [](const float* p) {
         const unsigned long long u = (unsigned long long)p;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     }
     __builtin_amdgcn_s_barrier();                                      // ... and so have everybody else's
     if (tile < t0) continue;
+    const float csmul = (do_cs && bq[buf] < a.colB) ? 1.0f : 0.0f;
     if (COUNTED) {
       // Fragment reads as inline asm with counted waits: for compiler-visible ds_reads hipcc puts
       // s_waitcnt lgkmcnt(0) in front of every other MFMA group, which also waits for the reads of the NEXT k-step
@@ -261,6 +270,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
         for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[kp & 1][tl].x, bfr[kp & 1].x, acc[tl]);
 #pragma unroll
         for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[kp & 1][tl].y, bfr[kp & 1].y, acc[tl]);
+        cs0 = fmaf(bfr[kp & 1].x, csmul, cs0);
+        cs1 = fmaf(bfr[kp & 1].y, csmul, cs1);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -285,6 +296,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tl = 0; tl < TPW; ++tl) acc[tl] = MfmaW<MF>::run(afr[kk & 1][tl], bfr[kk & 1], acc[tl]);
+        cs0 = fmaf(bfr[kk & 1], csmul, cs0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -308,6 +320,20 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     const int tap = tg * TPW + tl;
     const int ci = ci0 + e / MF, co = co0 + e % MF;
     if (ci < a.Cin && co < a.Cout) pout[((size_t)tap * a.Cin + ci) * a.Cout + co] = sum;
+  }
+  if (do_cs) {
+    // fold the 64 / MF pixel-parity lanes of each channel and the 4 waves, in a fixed order
+    __syncthreads();
+    red[tid] = cs0 + cs1;
+    __syncthreads();
+    if (tid < MF) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int hh = 0; hh < 64 / MF; ++hh) s += red[w * 64 + hh * MF + tid];
+      if (co0 + tid < a.Cout) a.colpart[(size_t)chunk * a.Cout + co0 + tid] = s;
+    }
   }
 }
 
