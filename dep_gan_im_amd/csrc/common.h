@@ -140,6 +140,26 @@ struct ConvPlan {
 };
 ConvPlan dg_plan_conv(int KS, int Cin, int Cout);
 
+// One weight-packing job of a batched launch (dg_pack_weights_batch): what dg_pack_weights takes, plus an optional
+// re-spacing of the channel-tile blocks in the destination (nt_stride elements between consecutive channel tiles;
+// 0 = dense) so that several sources can be interleaved per channel tile.
+struct PackJob {
+  const float* src;
+  float* dst;
+  const float* kscale;
+  int ntaps, srcI, srcO, io, transpose, flip;
+  int NT, CK, nCC, Kdim, Ndim;
+  unsigned total;       // packed floats of this job
+  unsigned per_nt;      // packed floats per channel tile (nCC * ntaps * NT * CK)
+  unsigned nt_stride;   // destination elements between channel tiles
+  unsigned blk0, nblk;  // first block and number of blocks of this job inside the batched grid
+};
+int dg_pack_job(const ConvPlan& pl, const float* src, int srcI, int srcO, int io, int transpose, int flip,
+                const float* kscale, float* dst, size_t nt_stride, PackJob* job);
+// jobs_dev: device copy of the array (blk0 / nblk filled by dg_pack_layout on the host copy before the upload)
+unsigned dg_pack_layout(PackJob* jobs_host, int njobs);
+int dg_pack_weights_batch(const PackJob* jobs_dev, int njobs, unsigned nblocks, hipStream_t st);
+
 // weight packing: src is HWIO (io=0) or HWOI (io=1, Conv2DTranspose layout)
 // roles: if transpose==0 the GEMM K index is the source I axis and N the O axis
 // (forward conv); if transpose==1 K is the source O axis and N the I axis

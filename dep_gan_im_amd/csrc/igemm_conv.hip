@@ -597,6 +597,77 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+// Batched form: every packed panel of a network in ONE launch (a refresh after an Adam step used to be ~130 launches
+// of a few microseconds each for the generator).  Block -> job by binary search over the jobs' first blocks.
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].blk0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackJob J = jobs[lo];
+  const unsigned b = blockIdx.x - J.blk0;
+  for (unsigned i = b * 256u + threadIdx.x; i < J.total; i += J.nblk * 256u) {
+    unsigned q = i;
+    const int k = (int)(q % J.CK);
+    q /= J.CK;
+    const int n = (int)(q % J.NT);
+    q /= J.NT;
+    const int tap = (int)(q % J.ntaps);
+    q /= J.ntaps;
+    const int cc = (int)(q % J.nCC);
+    const int nt = (int)(q / J.nCC);
+    const int kk = cc * J.CK + k, nn = nt * J.NT + n;
+    float v = 0.f;
+    if (kk < J.Kdim && nn < J.Ndim) {
+      const int ci = J.transpose ? nn : kk;
+      const int co = J.transpose ? kk : nn;
+      const int ts = J.flip ? (J.ntaps - 1 - tap) : tap;
+      const size_t off = (size_t)ts * J.srcI * J.srcO + (J.io ? ((size_t)co * J.srcI + ci) : ((size_t)ci * J.srcO + co));
+      v = J.src[off];
+      if (J.kscale) v *= J.kscale[kk];
+    }
+    J.dst[(size_t)nt * J.nt_stride + (i - (unsigned)nt * J.per_nt)] = v;
+  }
+}
+
+int dg_pack_job(const ConvPlan& pl, const float* src, int srcI, int srcO, int io, int transpose, int flip,
+                const float* kscale, float* dst, size_t nt_stride, PackJob* job) {
+  const int Kdim = transpose ? srcO : srcI, Ndim = transpose ? srcI : srcO;
+  if (Kdim != pl.Cin || Ndim != pl.Cout || pl.variant < 0 || pl.packedFloats >= (1ull << 31)) {
+    dg_set_error("dg_pack_job: plan (%d->%d) does not match source roles (%d->%d)", pl.Cin, pl.Cout, Kdim, Ndim);
+    return DG_ERR_ARG;
+  }
+  job->src = src; job->dst = dst; job->kscale = kscale;
+  job->ntaps = pl.KS * pl.KS; job->srcI = srcI; job->srcO = srcO; job->io = io; job->transpose = transpose;
+  job->flip = flip; job->NT = pl.NT; job->CK = pl.CK; job->nCC = pl.nCC; job->Kdim = Kdim; job->Ndim = Ndim;
+  job->total = (unsigned)pl.packedFloats;
+  job->per_nt = (unsigned)((size_t)pl.nCC * pl.KS * pl.KS * pl.NT * pl.CK);
+  job->nt_stride = nt_stride ? (unsigned)nt_stride : job->per_nt;
+  job->blk0 = job->nblk = 0;
+  return DG_OK;
+}
+
+unsigned dg_pack_layout(PackJob* jobs, int njobs) {
+  unsigned b = 0;
+  for (int i = 0; i < njobs; ++i) {
+    unsigned n = (jobs[i].total + 255u) / 256u;
+    if (n > 32u) n = 32u;            // grid-stride inside a job: ~1000 blocks for the whole generator
+    if (n < 1u) n = 1u;
+    jobs[i].blk0 = b;
+    jobs[i].nblk = n;
+    b += n;
+  }
+  return b;
+}
+
+int dg_pack_weights_batch(const PackJob* jobs_dev, int njobs, unsigned nblocks, hipStream_t st) {
+  if (njobs <= 0) return DG_OK;
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
 int dg_pack_weights(const ConvPlan& pl, const float* src, int srcI, int srcO, int io, int transpose, int flip,
                     const float* kscale, float* dst, hipStream_t st) {
   const int Kdim = transpose ? srcO : srcI, Ndim = transpose ? srcI : srcO;

@@ -89,6 +89,9 @@ struct DLayer {
 
 struct DNet {
   Net net;
+  PackJob* pack_jobs = nullptr;   // device table of this critic's packing jobs (built at the first refresh)
+  int n_pack = 0;
+  unsigned pack_blocks = 0;
   float* wpf[11];
   float* wpb[11];
   float *W[11], *b[11], *dW[11], *db[11];
@@ -115,6 +118,12 @@ struct depgan_ctx {
   NoiseGrads ng;
   NoiseActs na;
   float* derived = nullptr;       // BN affines
+  // device tables for the batched refresh launches (built at the first refresh; every pointer in them is stable)
+  PackJob* g_pack_jobs = nullptr;
+  int g_n_pack = 0;
+  unsigned g_pack_blocks = 0;
+  BnJob* g_bn_jobs = nullptr;
+  int g_n_bn = 0;
   float* heads_mean = nullptr;    // concatenated moving means of the head BNs
   float* dheads = nullptr;        // [B][1024]
   Tn attr;                        // generator output (B,H,W,1)

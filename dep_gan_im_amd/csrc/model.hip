@@ -548,70 +548,111 @@ static int build_critics(depgan_ctx* c) {
 // ---------------------------------------------------------------------------
 // derived state (BN affines, packed weights)
 // ---------------------------------------------------------------------------
+template <typename T>
+static int upload_table(depgan_ctx* c, const std::vector<T>& host, T** dev) {
+  float* p = nullptr;
+  DGCHECK(dmalloc(c, &p, (host.size() * sizeof(T) + 3) / 4 + 4));
+  HIPCHECK(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dev = reinterpret_cast<T*>(p);
+  return DG_OK;
+}
+
 int refresh_generator_bn(depgan_ctx* c) {
   Net& g = c->g;
   const float eps = 1e-3f;  // keras BatchNormalization default
-  NoiseParams& np = c->np;
-  DGCHECK(dg_bn_prepare(g.p("dense_bn_noise_1_add_f0/gamma"), g.p("dense_bn_noise_1_add_f0/beta"), np.mean0,
-                        g.p("dense_bn_noise_1_add_f0/moving_variance"), eps, (float*)np.s0, (float*)np.t0,
-                        (float*)np.rstd0, 32, c->st));
-  DGCHECK(dg_bn_prepare(g.p("dense_bn_noise_1_add_f1/gamma"), g.p("dense_bn_noise_1_add_f1/beta"), np.mean1,
-                        g.p("dense_bn_noise_1_add_f1/moving_variance"), eps, (float*)np.s1, (float*)np.t1,
-                        (float*)np.rstd1, 32, c->st));
-  for (int h = 0; h < NOISE_NHEADS; ++h) {
-    const std::string bn = std::string("dense_bn_noise_2_") + kHeadSfx[h];
-    const int c0 = np.col0[h], n = np.ncol[h];
-    DGCHECK(dg_bn_prepare(g.p(bn + "/gamma"), g.p(bn + "/beta"), g.p(bn + "/moving_mean"),
-                          g.p(bn + "/moving_variance"), eps, (float*)np.sh + c0, (float*)np.th + c0,
-                          (float*)np.rstdh + c0, n, c->st));
-    HIPCHECK(hipMemcpyAsync(c->heads_mean + c0, g.p(bn + "/moving_mean"), n * sizeof(float),
-                            hipMemcpyDeviceToDevice, c->st));
+  if (!c->g_bn_jobs) {
+    // every BatchNorm of the generator (2 trunk + 14 head BNs of the noise MLP, 24 conv BNs) as one launch
+    NoiseParams& np = c->np;
+    std::vector<BnJob> jobs;
+    jobs.push_back({g.p("dense_bn_noise_1_add_f0/gamma"), g.p("dense_bn_noise_1_add_f0/beta"), np.mean0,
+                    g.p("dense_bn_noise_1_add_f0/moving_variance"), (float*)np.s0, (float*)np.t0, (float*)np.rstd0,
+                    nullptr, 32});
+    jobs.push_back({g.p("dense_bn_noise_1_add_f1/gamma"), g.p("dense_bn_noise_1_add_f1/beta"), np.mean1,
+                    g.p("dense_bn_noise_1_add_f1/moving_variance"), (float*)np.s1, (float*)np.t1, (float*)np.rstd1,
+                    nullptr, 32});
+    for (int h = 0; h < NOISE_NHEADS; ++h) {
+      const std::string bn = std::string("dense_bn_noise_2_") + kHeadSfx[h];
+      const int c0 = np.col0[h], n = np.ncol[h];
+      jobs.push_back({g.p(bn + "/gamma"), g.p(bn + "/beta"), g.p(bn + "/moving_mean"), g.p(bn + "/moving_variance"),
+                      (float*)np.sh + c0, (float*)np.th + c0, (float*)np.rstdh + c0, c->heads_mean + c0, n});
+    }
+    for (size_t i = 0; i < c->gl.size(); ++i) {
+      GLayer& L = c->gl[i];
+      if (L.kind == G_CONV || L.kind == G_FILM || L.kind == G_DECONV)
+        jobs.push_back({L.gamma, L.beta, L.mean, L.var, L.s, L.t, L.rstd, nullptr, L.Cout});
+    }
+    c->g_n_bn = (int)jobs.size();
+    DGCHECK(upload_table(c, jobs, &c->g_bn_jobs));
   }
-  for (size_t i = 0; i < c->gl.size(); ++i) {
-    GLayer& L = c->gl[i];
-    if (L.kind == G_CONV || L.kind == G_FILM || L.kind == G_DECONV)
-      DGCHECK(dg_bn_prepare(L.gamma, L.beta, L.mean, L.var, eps, L.s, L.t, L.rstd, L.Cout, c->st));
-  }
-  return DG_OK;
+  return dg_bn_prepare_batch(c->g_bn_jobs, c->g_n_bn, eps, c->st);
 }
 
 int refresh_generator(depgan_ctx* c) {
   DGCHECK(net_requantize(c, c->g));
   DGCHECK(refresh_generator_bn(c));
-  for (size_t i = 0; i < c->gl.size(); ++i) {
-    GLayer& L = c->gl[i];
-    // backward packs carry the phase-0 BN scale; the learning-phase-1 path differentiates through the batch
-    // statistics instead and needs them unscaled
-    const float* ks = c->train_bn ? nullptr : L.s;
-    if (L.kind == G_CONV || L.kind == G_FILM) {
-      if (L.wpf[0]) DGCHECK(dg_pack_weights(L.pf, L.Wt, L.Cin, L.Cout, 0, 0, 0, nullptr, L.wpf[0], c->st));
-      if (L.wpb[0]) DGCHECK(dg_pack_weights(L.pb, L.Wt, L.Cin, L.Cout, 0, 1, 1, ks, L.wpb[0], c->st));
-    } else if (L.kind == G_DECONV) {
-      for (int t = 0; t < 4; ++t) {
-        const float* src = L.Wt + (size_t)t * L.Cout * L.Cin;  // (kh,kw,Cout,Cin)
-        DGCHECK(dg_pack_weights(L.pf, src, L.Cin, L.Cout, 1, 0, 0, nullptr, L.wpf[t], c->st));
-        DGCHECK(dg_pack_weights(L.pb, src, L.Cin, L.Cout, 1, 1, 0, ks, L.wpb[t], c->st));
-        if (L.wpb_all) {
-          // panel of channel tile nt, tap t -> [nt][t][chunk][n][k]: the K axis of the fused launch is (tap, channel)
-          const size_t blk = (size_t)L.pb.nCC * L.pb.NT * L.pb.CK * sizeof(float);
-          HIPCHECK(hipMemcpy2DAsync(reinterpret_cast<char*>(L.wpb_all) + t * blk, 4 * blk, L.wpb[t], blk, blk,
-                                    (size_t)L.pb.nNT, hipMemcpyDeviceToDevice, c->st));
+  if (!c->g_pack_jobs) {
+    std::vector<PackJob> jobs;
+    PackJob j;
+    for (size_t i = 0; i < c->gl.size(); ++i) {
+      GLayer& L = c->gl[i];
+      // backward packs carry the phase-0 BN scale; the learning-phase-1 path differentiates through the batch
+      // statistics instead and needs them unscaled
+      const float* ks = c->train_bn ? nullptr : L.s;
+      if (L.kind == G_CONV || L.kind == G_FILM) {
+        if (L.wpf[0]) {
+          DGCHECK(dg_pack_job(L.pf, L.Wt, L.Cin, L.Cout, 0, 0, 0, nullptr, L.wpf[0], 0, &j));
+          jobs.push_back(j);
+        }
+        if (L.wpb[0]) {
+          DGCHECK(dg_pack_job(L.pb, L.Wt, L.Cin, L.Cout, 0, 1, 1, ks, L.wpb[0], 0, &j));
+          jobs.push_back(j);
+        }
+      } else if (L.kind == G_DECONV) {
+        for (int t = 0; t < 4; ++t) {
+          const float* src = L.Wt + (size_t)t * L.Cout * L.Cin;  // (kh,kw,Cout,Cin)
+          DGCHECK(dg_pack_job(L.pf, src, L.Cin, L.Cout, 1, 0, 0, nullptr, L.wpf[t], 0, &j));
+          jobs.push_back(j);
+          if (L.wpb_all) {
+            // panel of channel tile nt, tap t -> [nt][t][chunk][n][k]: the K axis of the fused backward-data launch
+            // is (tap, channel); the per-tap panels are written straight into that interleaved layout
+            const size_t blk = (size_t)L.pb.nCC * L.pb.NT * L.pb.CK;
+            DGCHECK(dg_pack_job(L.pb, src, L.Cin, L.Cout, 1, 1, 0, ks, L.wpb_all + t * blk, 4 * blk, &j));
+          } else {
+            DGCHECK(dg_pack_job(L.pb, src, L.Cin, L.Cout, 1, 1, 0, ks, L.wpb[t], 0, &j));
+          }
+          jobs.push_back(j);
         }
       }
     }
+    c->g_n_pack = (int)jobs.size();
+    c->g_pack_blocks = dg_pack_layout(jobs.data(), c->g_n_pack);
+    DGCHECK(upload_table(c, jobs, &c->g_pack_jobs));
   }
-  return DG_OK;
+  return dg_pack_weights_batch(c->g_pack_jobs, c->g_n_pack, c->g_pack_blocks, c->st);
 }
 
 static int refresh_critic(depgan_ctx* c, DNet& D) {
   if (c->dl.empty()) return DG_OK;  // supervised context: no critics
   DGCHECK(net_requantize(c, D.net));
-  for (int l = 0; l < 11; ++l) {
-    const DLayer& L = c->dl[l];
-    if (D.wpf[l]) DGCHECK(dg_pack_weights(L.pf, D.W[l], L.Cin, L.Cout, 0, 0, 0, nullptr, D.wpf[l], c->st));
-    if (D.wpb[l]) DGCHECK(dg_pack_weights(L.pb, D.W[l], L.Cin, L.Cout, 0, 1, 1, nullptr, D.wpb[l], c->st));
+  if (!D.pack_jobs) {
+    std::vector<PackJob> jobs;
+    PackJob j;
+    for (int l = 0; l < 11; ++l) {
+      const DLayer& L = c->dl[l];
+      if (D.wpf[l]) {
+        DGCHECK(dg_pack_job(L.pf, D.W[l], L.Cin, L.Cout, 0, 0, 0, nullptr, D.wpf[l], 0, &j));
+        jobs.push_back(j);
+      }
+      if (D.wpb[l]) {
+        DGCHECK(dg_pack_job(L.pb, D.W[l], L.Cin, L.Cout, 0, 1, 1, nullptr, D.wpb[l], 0, &j));
+        jobs.push_back(j);
+      }
+    }
+    D.n_pack = (int)jobs.size();
+    D.pack_blocks = dg_pack_layout(jobs.data(), D.n_pack);
+    DGCHECK(upload_table(c, jobs, &D.pack_jobs));
   }
-  return DG_OK;
+  return dg_pack_weights_batch(D.pack_jobs, D.n_pack, D.pack_blocks, c->st);
 }
 
 // ---------------------------------------------------------------------------

@@ -41,6 +41,13 @@ int dg_critic_tail_wgrad(const float* src, const float* w9, const float* b9, con
 
 // column sums of an NHWC view: out[c] (+)= scale[c] * sum_{b,y,x} v[b,y,x,c]; raw (optional) gets the bare sum.
 // scratch: 1024*C floats
+// one BatchNorm of a batched dg_bn_prepare_batch launch; mean_copy (optional) receives a copy of the moving mean
+struct BnJob {
+  const float *gamma, *beta, *mean, *var;
+  float *s, *t, *rstd, *mean_copy;
+  int C;
+};
+int dg_bn_prepare_batch(const BnJob* jobs_dev, int njobs, float eps, hipStream_t st);
 int dg_colsum_finish(const float* part, int nb, int C, const float* scale, float* out, float* raw, int accumulate,
                      hipStream_t st);
 int dg_colsum(TView v, int B, int H, int W, int C, const float* scale, float* out, float* raw, int accumulate,

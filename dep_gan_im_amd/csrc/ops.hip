@@ -165,6 +165,25 @@ int dg_bn_prepare(const float* gamma, const float* beta, const float* mean, cons
   return DG_OK;
 }
 
+// all BatchNorms of a network in one launch: block = one BatchNorm
+__global__ __launch_bounds__(256) void bn_prepare_batch_kernel(const BnJob* __restrict__ jobs, float eps) {
+  const BnJob J = jobs[blockIdx.x];
+  for (int c = threadIdx.x; c < J.C; c += 256) {
+    const float r = 1.0f / sqrtf(J.var[c] + eps);
+    const float sc = J.gamma[c] * r;
+    J.s[c] = sc;
+    J.t[c] = J.beta[c] - J.mean[c] * sc;
+    J.rstd[c] = r;
+    if (J.mean_copy) J.mean_copy[c] = J.mean[c];
+  }
+}
+int dg_bn_prepare_batch(const BnJob* jobs_dev, int njobs, float eps, hipStream_t st) {
+  if (njobs <= 0) return DG_OK;
+  hipLaunchKernelGGL(bn_prepare_batch_kernel, dim3(njobs), dim3(256), 0, st, jobs_dev, eps);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // generator head
 // ---------------------------------------------------------------------------
