@@ -177,6 +177,10 @@ size_t dg_wgrad_part_floats(int KS, int B, int H, int W, int Cin, int Cout);
 int dg_wgrad(int KS, const WgradArgs& a, int* nchunks, hipStream_t st);
 // out[(tap,ci,co)] (+)= scale[co] * sum_chunks part ; raw (optional) gets the unscaled sum.
 // oi=1 writes [tap][co][ci] (Conv2DTranspose kernel layout) instead of [tap][ci][co].
+// slab reduction and (colpart non-null) the column-sum finish of the same weight-gradient launch, as ONE launch
+int dg_wgrad_finish(const float* part, int nchunks, int ntaps, int Cin, int Cout, const float* scale, float* out,
+                    float* raw, int accumulate, int oi, const float* colpart, int colC, const float* colscale,
+                    float* colout, float* colraw, hipStream_t st);
 int dg_wgrad_reduce(const float* part, int nchunks, int ntaps, int Cin, int Cout, const float* scale, float* out,
                     float* raw, int accumulate, int oi, hipStream_t st);
 

@@ -199,10 +199,10 @@ int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, in
       ProfScope ps(c, 1, fl, lb);
       DGCHECK(dg_wgrad(KS, a, &nch, c->st));
     }
-    if (cs) {
-      ProfScope ps(c, 2, 0.0, "colsum");
-      DGCHECK(dg_colsum_finish(c->scratch, nch, Cout, cs->scale, cs->out, cs->raw, 0, c->st));
-    }
+    // slab reduction and the column-sum finish in one launch
+    ProfScope ps(c, 2, 0.0, "slab reduce");
+    return dg_wgrad_finish(c->part, nch, KS * KS, Cin, Cout, scale, out, raw, accumulate, oi, cs ? c->scratch : nullptr,
+                           Cout, cs ? cs->scale : nullptr, cs ? cs->out : nullptr, cs ? cs->raw : nullptr, c->st);
   } else {
     if (dg_wgrad_small_part_floats(KS, N, H, W, Cin, Cout) > c->partFloats) {
       dg_set_error("wgrad slab workspace too small");

@@ -48,8 +48,6 @@ struct BnJob {
   int C;
 };
 int dg_bn_prepare_batch(const BnJob* jobs_dev, int njobs, float eps, hipStream_t st);
-int dg_colsum_finish(const float* part, int nb, int C, const float* scale, float* out, float* raw, int accumulate,
-                     hipStream_t st);
 int dg_colsum(TView v, int B, int H, int W, int C, const float* scale, float* out, float* raw, int accumulate,
               float* scratch, hipStream_t st);
 

@@ -475,14 +475,6 @@ static int colsum_impl(TView v, int B, int H, int W, int C, const float* scale, 
   return DG_OK;
 }
 
-// second half of dg_colsum alone, for partial rows [nb][C] produced elsewhere (the weight-gradient kernel)
-int dg_colsum_finish(const float* part, int nb, int C, const float* scale, float* out, float* raw, int accumulate,
-                     hipStream_t st) {
-  hipLaunchKernelGGL(colsum_final, dim3(C), dim3(256), 0, st, part, nb, C, scale, out, raw, accumulate);
-  HIPCHECK(hipGetLastError());
-  return DG_OK;
-}
-
 int dg_colsum(TView v, int B, int H, int W, int C, const float* scale, float* out, float* raw, int accumulate,
               float* scratch, hipStream_t st) {
   return colsum_impl(v, B, H, W, C, scale, out, raw, accumulate, nullptr, scratch, st);

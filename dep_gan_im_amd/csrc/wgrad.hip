@@ -434,64 +434,87 @@ int dg_wgrad(int KS, const WgradArgs& a_in, int* nchunks_out, hipStream_t st) {
 // ---------------------------------------------------------------------------
 // deterministic slab reduction
 // ---------------------------------------------------------------------------
-// stage: out[g][i] = sum_{c in [g*per, min((g+1)*per, nin))} in[c][i]
-__global__ void slab_reduce_stage(const float* __restrict__ in, int nin, size_t n, float* __restrict__ out, int per) {
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int g = blockIdx.y;
-  const int c0 = g * per, c1 = min(c0 + per, nin);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int c = c0;
-  for (; c + 3 < c1; c += 4) {
-    s0 += in[(size_t)c * n + i];
-    s1 += in[(size_t)(c + 1) * n + i];
-    s2 += in[(size_t)(c + 2) * n + i];
-    s3 += in[(size_t)(c + 3) * n + i];
+// One launch finishes a weight gradient: blocks [0, nbr) reduce the slabs -- a block is 64 output elements x 4 slices of
+// the chunk range, every thread sums its slice front to back (4 independent accumulators), the 4 slice sums are added in
+// a fixed order -- and, when the launch carried column sums, blocks [nbr, nbr + Cout) reduce the [nchunks][Cout]
+// partial rows of one channel each.  No float atomics anywhere: a step is bit-reproducible run to run.
+struct ColFin {
+  const float* part;     // [nb][C] partial rows (null: none)
+  const float* scale;
+  float *out, *raw;
+  int nb, C;
+};
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ in, int nin, int ntaps, int Cin,
+                                                          int Cout, const float* __restrict__ scale,
+                                                          float* __restrict__ out, float* __restrict__ raw,
+                                                          int accumulate, int oi, unsigned nbr, ColFin cf) {
+  __shared__ float sh[256];
+  if (blockIdx.x >= nbr) {
+    // column-sum finish: one channel per block
+    const int c = (int)(blockIdx.x - nbr);
+    float s = 0.f;
+    for (int b = threadIdx.x; b < cf.nb; b += 256) s += cf.part[(size_t)b * cf.C + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float t = sh[0];
+      if (cf.raw) cf.raw[c] = t;
+      if (cf.out) cf.out[c] = cf.scale ? t * cf.scale[c] : t;
+    }
+    return;
   }
-  for (; c < c1; ++c) s0 += in[(size_t)c * n + i];
-  out[(size_t)g * n + i] = (s0 + s1) + (s2 + s3);
+  const size_t n = (size_t)ntaps * Cin * Cout;
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + el;
+  const int per = (nin + 3) >> 2;
+  const int c0 = sl * per, c1 = min(c0 + per, nin);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int c = c0;
+    for (; c + 3 < c1; c += 4) {
+      s0 += in[(size_t)c * n + i];
+      s1 += in[(size_t)(c + 1) * n + i];
+      s2 += in[(size_t)(c + 2) * n + i];
+      s3 += in[(size_t)(c + 3) * n + i];
+    }
+    for (; c < c1; ++c) s0 += in[(size_t)c * n + i];
+  }
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    const float s = (sh[el] + sh[64 + el]) + (sh[128 + el] + sh[192 + el]);
+    const int co = (int)(i % Cout);
+    const int ci = (int)((i / Cout) % Cin);
+    const int tap = (int)(i / ((size_t)Cout * Cin));
+    const size_t o = oi ? (((size_t)tap * Cout + co) * Cin + ci) : i;
+    if (raw) raw[o] = s;
+    if (out) {
+      float v = scale ? s * scale[co] : s;
+      if (accumulate) v += out[o];
+      out[o] = v;
+    }
+  }
 }
 
-__global__ void slab_reduce_final(const float* __restrict__ in, int nin, int ntaps, int Cin, int Cout,
-                                  const float* __restrict__ scale, float* __restrict__ out, float* __restrict__ raw,
-                                  int accumulate, int oi) {
+int dg_wgrad_finish(const float* part, int nchunks, int ntaps, int Cin, int Cout, const float* scale, float* out,
+                    float* raw, int accumulate, int oi, const float* colpart, int colC, const float* colscale,
+                    float* colout, float* colraw, hipStream_t st) {
   const size_t n = (size_t)ntaps * Cin * Cout;
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int c = 0; c < nin; ++c) s += in[(size_t)c * n + i];
-  const int co = (int)(i % Cout);
-  const int ci = (int)((i / Cout) % Cin);
-  const int tap = (int)(i / ((size_t)Cout * Cin));
-  const size_t o = oi ? (((size_t)tap * Cout + co) * Cin + ci) : i;
-  if (raw) raw[o] = s;
-  if (out) {
-    float v = scale ? s * scale[co] : s;
-    if (accumulate) v += out[o];
-    out[o] = v;
-  }
+  const unsigned nbr = (unsigned)((n + 63) / 64);
+  ColFin cf = {colpart, colscale, colout, colraw, nchunks, colC};
+  const unsigned ncol = colpart ? (unsigned)colC : 0u;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(nbr + ncol), dim3(256), 0, st, part, nchunks, ntaps, Cin, Cout, scale, out,
+                     raw, accumulate, oi, nbr, cf);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
 }
 
 int dg_wgrad_reduce(const float* part, int nchunks, int ntaps, int Cin, int Cout, const float* scale, float* out,
                     float* raw, int accumulate, int oi, hipStream_t st) {
-  const size_t n = (size_t)ntaps * Cin * Cout;
-  const int bx = (int)((n + 255) / 256);
-  const float* src = part;
-  int nin = nchunks;
-  if (nchunks > 48) {
-    // first stage writes behind the slabs it reads?  No: it writes into the
-    // head of the same buffer only after every group has been read, which a
-    // single launch cannot order -- so stage 1 writes to the tail region.
-    const int per = 32;
-    const int groups = cdiv(nchunks, per);
-    float* tmp = const_cast<float*>(part) + (size_t)nchunks * n;  // caller reserves 1/32 extra (see part sizing)
-    hipLaunchKernelGGL(slab_reduce_stage, dim3(bx, groups), dim3(256), 0, st, part, nchunks, n, tmp, per);
-    HIPCHECK(hipGetLastError());
-    src = tmp;
-    nin = groups;
-  }
-  hipLaunchKernelGGL(slab_reduce_final, dim3(bx), dim3(256), 0, st, src, nin, ntaps, Cin, Cout, scale, out, raw,
-                     accumulate, oi);
-  HIPCHECK(hipGetLastError());
-  return DG_OK;
+  return dg_wgrad_finish(part, nchunks, ntaps, Cin, Cout, scale, out, raw, accumulate, oi, nullptr, 0, nullptr, nullptr,
+                         nullptr, st);
 }
