@@ -525,7 +525,7 @@ size_t dg_wgrad_small_part_floats(int KS, int B, int H, int W, int Cin, int Cout
   int nTiles, tpc, nch;
   small_chunking(B, H, W, &nTiles, &tpc, &nch);
   const size_t slab = (size_t)KS * KS * Cin * Cout;
-  return (size_t)nch * slab + (size_t)cdiv(nch, 32) * slab;
+  return (size_t)nch * slab;
 }
 
 int dg_wgrad_small(int KS, const WgradArgs& a_in, int* nchunks, hipStream_t st) {

@@ -47,7 +47,7 @@ struct MfmaW<16> {
 // load and MFMA phases of co-resident workgroups ran in lockstep, so the matrix pipe idled during every staging phase
 // (85 TFLOP/s).  Here the next tile is copied global -> LDS by the DMA path (no VGPR destination, no ds_write pass)
 // into the second of two LDS buffers while the MFMAs of the current tile run: two raw barriers and one counted vmcnt
-// per tile, accumulators in AGPRs, no spills (113-117 TFLOP/s on the 3x3 layers).
+// per tile, accumulators in AGPRs, no spills (117-121 TFLOP/s on the 3x3 layers inside the step).
 // The LDS image is the [pixel][MF] one of the header, which is lane-linear per wave-instruction (64 lanes x 16 B =
 // 64*16/(4 MF) pixels) as the DMA requires; out-of-image pixels and channel tails carry an out-of-range buffer offset
 // instead (the per-lane SOURCE address is free and the hardware returns zeros for it), so no lane is ever masked and
@@ -382,7 +382,7 @@ size_t dg_wgrad_part_floats(int KS, int B, int H, int W, int Cin, int Cout) {
   int nTiles, tpc, nch, gy;
   chunking(v, B, H, W, Cin, Cout, &nTiles, &tpc, &nch, &gy);
   const size_t slab = (size_t)KS * KS * Cin * Cout;
-  return (size_t)nch * slab + (size_t)cdiv(nch, 32) * slab;  // + room for the first reduction stage
+  return (size_t)nch * slab;
 }
 
 template <int MF, int KS, int TPW, int TH>
