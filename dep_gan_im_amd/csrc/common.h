@@ -61,6 +61,9 @@ struct Epilogue {
   TView mask;
   int relu;
   int accumulate;
+  // igemm only: when pool.p is non-null the 2x2 / stride-2 max-pool of the final output is written here as well
+  // (view of (H/2, W/2) pixels; H and W must be even).  Saves the pooling pass its read of the whole output.
+  TView pool;
 };
 
 struct ConvArgs {

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_ker
   const Epilogue& e = a.ep;
   const bool affine = e.scale != nullptr, film = e.film_mul != nullptr, relu = e.relu != 0, accum = e.accumulate != 0;
   const bool has_bias = e.bias != nullptr, has_pre = e.out_pre.p != nullptr, has_res = e.res.p != nullptr,
-             has_msk = e.mask.p != nullptr;
+             has_msk = e.mask.p != nullptr, has_pool = e.pool.p != nullptr;
   const int oyw = ty0 + 4 * wvu;
   const bool full = (ty0 + 16 <= a.H) && (tx0 + 16 <= a.W);
   if (co < a.Cout) {
@@ -384,6 +384,13 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_ker
     const __amdgpu_buffer_rsrc_t r_pre = mk(has_pre ? e.out_pre.p + view_off(e.out_pre, b, oyw, tx0) : a.out.p);
     const __amdgpu_buffer_rsrc_t r_res = mk(has_res ? e.res.p + view_off(e.res, b, oyw, tx0) : a.out.p);
     const __amdgpu_buffer_rsrc_t r_msk = mk(has_msk ? e.mask.p + view_off(e.mask, b, oyw, tx0) : a.out.p);
+    // fused 2x2 max-pool: the wave's 4 x 16 block holds whole pool windows (tile origins are multiples of 16); the
+    // two rows of a window are two passes apart, its two columns 8 lanes (NT = 32) or 4 lanes (NT = 16) apart
+    const __amdgpu_buffer_rsrc_t r_pool =
+        mk(has_pool ? e.pool.p + view_off(e.pool, b, oyw >> 1, tx0 >> 1) : a.out.p);
+    const int lo_pool = has_pool ? 4 * ((pl0 >> 1) * (int)e.pool.sX + co) : 0;
+    const int sY_pool = 4 * (int)e.pool.sY, sX_pool = 4 * (int)e.pool.sX;
+    f32x4 vrow = {0.f, 0.f, 0.f, 0.f};
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
       const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
@@ -398,10 +405,12 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_ker
     const int sY_msk = 4 * (int)e.mask.sY, sX_msk = 4 * (int)e.mask.sX;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      // pass p covers pixels (py, px0 .. px0 + PPP) of the wave's 4 x 16 block
-      const int py = (p * PPP) >> 4, px0 = (p * PPP) & 15;
+      // pass p covers pixels (py, px0 .. px0 + PPP) of the wave's 4 x 16 block; the passes walk the block so that
+      // the two rows of a 2x2 pool window are consecutive passes (row pair, then the next column part)
+      constexpr int RP = 16 / PPP;      // passes per pixel row
+      const int py = (p & 1) + 2 * (p / (2 * RP)), px0 = ((p >> 1) % RP) * PPP;
       const bool ok = full || (oyw + py < a.H && tx0 + px0 + pl0 < a.W);
-      f32x4 v = *reinterpret_cast<const f32x4*>(es + (p * PPP + pl0) * CP + c4);
+      f32x4 v = *reinterpret_cast<const f32x4*>(es + (py * 16 + px0 + pl0) * CP + c4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         v[k] += bias4[k];
@@ -438,6 +447,19 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_ker
         for (int k = 0; k < 4; ++k) v[k] += old[k];
       }
       if (ok) st(r_out, lo_out, so, v);
+      if (has_pool) {
+        if ((py & 1) == 0) {
+          vrow = v;
+        } else {
+          f32x4 m;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float t = fmaxf(vrow[k], v[k]);
+            m[k] = fmaxf(t, __shfl_xor(t, LPP, 64));
+          }
+          if (ok && (pl0 & 1) == 0) st(r_pool, lo_pool, (py >> 1) * sY_pool + (px0 >> 1) * sX_pool, m);
+        }
+      }
     }
   }
   if (dbg && tid == 0) {
@@ -545,6 +567,10 @@ int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
   if (misaligned(a.in) || misaligned(a.out) || misaligned(a.ep.res) || misaligned(a.ep.mask) ||
       misaligned(a.ep.out_pre) || (a.Cout % 4) || (a.ep.film_mul && (a.ep.film_ld % 4))) {
     dg_set_error("dg_conv_igemm: views must be 16-byte aligned (pointers, strides and Cout multiples of 4 floats)");
+    return DG_ERR_ARG;
+  }
+  if (a.ep.pool.p && ((a.H | a.W) & 1 || misaligned(a.ep.pool) || a.groups > 1)) {
+    dg_set_error("dg_conv_igemm: fused max-pool needs even H, W and a 16-byte aligned pooled view");
     return DG_ERR_ARG;
   }
   if (a.cpt > 0) {

@@ -105,7 +105,8 @@ int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
   // algorithmic bytes: every operand the epilogue names read once, every result written once, weights once
   const double px = 4.0 * a.B * a.H * a.W;
   const double by = px * a.Cin + ng * (px * a.Cout * (1 + (a.ep.res.p ? 1 : 0) + (a.ep.mask.p ? 1 : 0) +
-                                                      (a.ep.out_pre.p ? 1 : 0) + (a.ep.accumulate ? 1 : 0)) +
+                                                      (a.ep.out_pre.p ? 1 : 0) + (a.ep.accumulate ? 1 : 0) +
+                                                      (a.ep.pool.p ? 0.25 : 0)) +
                                           4.0 * KS * KS * a.Cin * a.Cout);
   if (pl.variant >= 0) {
     ProfScope ps(c, 0, fl, lb, by);
@@ -143,7 +144,7 @@ int deconv_bwd_data(depgan_ctx* c, GLayer& L, TView dsrc, int n) {
 
 void zero_ep(Epilogue* e) {
   memset(e, 0, sizeof(*e));
-  e->out_pre = e->res = e->mask = null_view();
+  e->out_pre = e->res = e->mask = e->pool = null_view();
 }
 
 TView view_offset(TView v, long samples) {
@@ -663,6 +664,7 @@ int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u
     ProfScope ps(c, 2, 0.0);
     DGCHECK(dg_noise_fwd(c->np, z, c->na, n, c->st));
   }
+  bool pooled_by_conv = false;
   for (size_t i = 0; i < c->gl.size(); ++i) {
     GLayer& L = c->gl[i];
     if (L.kind == G_CONV || L.kind == G_FILM) {
@@ -682,12 +684,18 @@ int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u
       }
       if (L.pf.variant >= 0) {
         a.w = L.wpf[0];
+        // the 2x2 max-pool that follows (gen_1 / gen_3 / gen_5, GT:409/422/435) rides in this launch's epilogue
+        if (i + 1 < c->gl.size() && c->gl[i + 1].kind == G_POOL && c->gl[i + 1].skip_of == (int)i &&
+            !((L.H | L.W) & 1))
+          a.ep.pool = c->gl[i + 1].out;
       } else {
         a.w = L.Wt;
         a.wsT = (long)L.Cin * L.Cout; a.wsI = L.Cout; a.wsO = 1; a.flip = 0;
       }
+      pooled_by_conv = a.ep.pool.p != nullptr;
       DGCHECK(conv_launch(c, L.pf, a, 3));
     } else if (L.kind == G_POOL) {
+      if (pooled_by_conv && L.skip_of == (int)i - 1) continue;
       ProfScope ps(c, 2, 0.0);
       DGCHECK(dg_maxpool(c->gl[L.skip_of].out, L.out, n, L.H / 2, L.W / 2, L.Cout, c->st));
     } else if (L.kind == G_DECONV) {
@@ -809,12 +817,13 @@ static int d_forward(depgan_ctx* c, DNet& D, const float* img, long s0, int N) {
     a.ep.relu = 1;
     if (L.pf.variant >= 0) {
       a.w = D.wpf[l];
+      if (L.pool && !((L.H | L.W) & 1)) a.ep.pool = view_offset(c->d_pool[l].view(), s0);   // pooled in the epilogue
     } else {
       a.w = D.W[l];
       a.wsT = (long)L.Cin * L.Cout; a.wsI = L.Cout; a.wsO = 1; a.flip = 0;
     }
     DGCHECK(conv_launch(c, L.pf, a, L.KS));
-    if (L.pool) {
+    if (L.pool && !a.ep.pool.p) {
       ProfScope ps(c, 2, 0.0);
       DGCHECK(dg_maxpool(a.out, view_offset(c->d_pool[l].view(), s0), N, L.H / 2, L.W / 2, L.Cout, c->st));
     }
