@@ -240,17 +240,21 @@ int dg_head_bwd(const float* dpre, const float* w, const float* a, float* dz, lo
 // ---------------------------------------------------------------------------
 // critic tail
 // ---------------------------------------------------------------------------
-__global__ void critic_tail_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w9,
-                                       const float* __restrict__ b9, const float* __restrict__ wd,
-                                       const float* __restrict__ bd, float* __restrict__ t9, float* __restrict__ out,
-                                       int HW, int C) {
-  __shared__ float sh4[4];
+// One block per sample, 16 waves, one pixel per wave and iteration: with 4 waves the 256 pixels of a sample were 64
+// dependent load -> wave-reduce rounds per block and the launch was latency-bound (40 us for 14 MB).
+__global__ __launch_bounds__(1024) void critic_tail_fwd_kernel(const float* __restrict__ a,
+                                                               const float* __restrict__ w9,
+                                                               const float* __restrict__ b9,
+                                                               const float* __restrict__ wd,
+                                                               const float* __restrict__ bd, float* __restrict__ t9,
+                                                               float* __restrict__ out, int HW, int C) {
+  __shared__ float sh16[16];
   const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* an = a + (size_t)n * HW * C;
   f32x4 wv9 = {0.f, 0.f, 0.f, 0.f};
   if (lane * 4 < C) wv9 = *reinterpret_cast<const f32x4*>(w9 + lane * 4);
   float part = 0.f;
-  for (int p = wv; p < HW; p += 4) {
+  for (int p = wv; p < HW; p += 16) {
     float v = 0.f;
     if (lane * 4 < C) {
       const f32x4 av = *reinterpret_cast<const f32x4*>(an + (size_t)p * C + lane * 4);
@@ -263,13 +267,19 @@ __global__ void critic_tail_fwd_kernel(const float* __restrict__ a, const float*
       part += v * wd[p];
     }
   }
-  const float tot = block_sum(part, sh4);
-  if (threadIdx.x == 0) out[n] = tot + bd[0];
+  if (lane == 0) sh16[wv] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += sh16[w];
+    out[n] = tot + bd[0];
+  }
 }
 int dg_critic_tail_fwd(const float* a, const float* w9, const float* b9, const float* wd, const float* bd, float* t9,
                        float* out, int N, int HW, int C, hipStream_t st) {
   if ((C % 4) || C > 256) { dg_set_error("dg_critic_tail_fwd: C must be a multiple of 4 and <= 256"); return DG_ERR_ARG; }
-  hipLaunchKernelGGL(critic_tail_fwd_kernel, dim3(N), dim3(256), 0, st, a, w9, b9, wd, bd, t9, out, HW, C);
+  hipLaunchKernelGGL(critic_tail_fwd_kernel, dim3(N), dim3(1024), 0, st, a, w9, b9, wd, bd, t9, out, HW, C);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
@@ -300,18 +310,20 @@ int dg_critic_tail_bwd(const float* a, const float* w9, const float* wd, const f
   return DG_OK;
 }
 
-// per-sample partial sums
-__global__ void critic_tail_wgrad_partial(const float* __restrict__ src, const float* __restrict__ w9,
-                                          const float* __restrict__ wd, float* __restrict__ pw9,
-                                          float* __restrict__ pwd, int HW, int C) {
-  __shared__ float red[4 * 256];
+// per-sample partial sums (16 waves per block, as the forward)
+__global__ __launch_bounds__(1024) void critic_tail_wgrad_partial(const float* __restrict__ src,
+                                                                  const float* __restrict__ w9,
+                                                                  const float* __restrict__ wd,
+                                                                  float* __restrict__ pw9, float* __restrict__ pwd,
+                                                                  int HW, int C) {
+  __shared__ float red[16 * 256];
   const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* sn = src + (size_t)n * HW * C;
   f32x4 wv9 = {0.f, 0.f, 0.f, 0.f};
   const bool act = lane * 4 < C;
   if (act) wv9 = *reinterpret_cast<const f32x4*>(w9 + lane * 4);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int p = wv; p < HW; p += 4) {
+  for (int p = wv; p < HW; p += 16) {
     float v = 0.f;
     if (act) {
       const f32x4 av = *reinterpret_cast<const f32x4*>(sn + (size_t)p * C + lane * 4);
@@ -326,31 +338,47 @@ __global__ void critic_tail_wgrad_partial(const float* __restrict__ src, const f
 #pragma unroll
   for (int k = 0; k < 4; ++k) red[wv * 256 + lane * 4 + k] = acc[k];
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256)
-    pw9[(size_t)n * C + c] = (red[c] + red[256 + c]) + (red[512 + c] + red[768 + c]);
+  for (int c = threadIdx.x; c < C; c += 1024) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w * 256 + c];
+    pw9[(size_t)n * C + c] = s;
+  }
 }
-__global__ void critic_tail_wgrad_final(const float* __restrict__ pw9, const float* __restrict__ pwd,
-                                        const float* __restrict__ coefs, int per, int add_bias_terms,
-                                        int accumulate, const float* __restrict__ b9, const float* __restrict__ wd,
-                                        float* __restrict__ dw9, float* __restrict__ db9, float* __restrict__ dwd,
-                                        float* __restrict__ dbd, int N, int HW, int C) {
+// One wave per output element (C kernel taps of dw9, then HW entries of dwd): lanes split the samples, wave reduction
+// in a fixed order.  The last block also forms the two bias gradients.
+__global__ __launch_bounds__(256) void critic_tail_wgrad_final(const float* __restrict__ pw9,
+                                                               const float* __restrict__ pwd,
+                                                               const float* __restrict__ coefs, int per,
+                                                               int add_bias_terms, int accumulate,
+                                                               const float* __restrict__ b9,
+                                                               const float* __restrict__ wd, float* __restrict__ dw9,
+                                                               float* __restrict__ db9, float* __restrict__ dwd,
+                                                               float* __restrict__ dbd, int N, int HW, int C) {
   __shared__ float sh4[4];
-  float csum = 0.f;
-  for (int n = 0; n < N; ++n) csum += coefs[n / per];
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float csum = 0.f;                                  // sum_n coefs[n / per], the same value in every thread
+  for (int g = 0; g * per < N; ++g) csum += coefs[g] * (float)min(per, N - g * per);
+  const int o = blockIdx.x * 4 + wv;
+  if (o < C + HW) {
+    const bool isw = o < C;
+    const float* src = isw ? pw9 + o : pwd + (o - C);
+    const int ld = isw ? C : HW;
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s += coefs[n / per] * pw9[(size_t)n * C + c];
-    dw9[c] = accumulate ? dw9[c] + s : s;
+    for (int n = lane; n < N; n += 64) s = fmaf(coefs[n / per], src[(size_t)n * ld], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+      if (isw) {
+        dw9[o] = accumulate ? dw9[o] + s : s;
+      } else {
+        if (add_bias_terms) s += b9[0] * csum;
+        dwd[o - C] = accumulate ? dwd[o - C] + s : s;
+      }
+    }
   }
-  float wsum = 0.f;
-  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += coefs[n / per] * pwd[(size_t)n * HW + p];
-    if (add_bias_terms) s += b9[0] * csum;
-    dwd[p] = accumulate ? dwd[p] + s : s;
-    wsum += wd[p];
-  }
-  if (add_bias_terms) {
+  if (add_bias_terms && blockIdx.x == gridDim.x - 1) {
+    float wsum = 0.f;
+    for (int p = threadIdx.x; p < HW; p += 256) wsum += wd[p];
     wsum = block_sum(wsum, sh4);
     if (threadIdx.x == 0) {
       db9[0] = accumulate ? db9[0] + csum * wsum : csum * wsum;
@@ -364,9 +392,9 @@ int dg_critic_tail_wgrad(const float* src, const float* w9, const float* b9, con
   if ((C % 4) || C > 256) { dg_set_error("dg_critic_tail_wgrad: C must be a multiple of 4 and <= 256"); return DG_ERR_ARG; }
   float* pw9 = scratch;
   float* pwd = scratch + (size_t)N * C;
-  hipLaunchKernelGGL(critic_tail_wgrad_partial, dim3(N), dim3(256), 0, st, src, w9, wd, pw9, pwd, HW, C);
+  hipLaunchKernelGGL(critic_tail_wgrad_partial, dim3(N), dim3(1024), 0, st, src, w9, wd, pw9, pwd, HW, C);
   HIPCHECK(hipGetLastError());
-  hipLaunchKernelGGL(critic_tail_wgrad_final, dim3(1), dim3(256), 0, st, pw9, pwd, coefs, per, add_bias_terms,
+  hipLaunchKernelGGL(critic_tail_wgrad_final, dim3(cdiv(C + HW, 4)), dim3(256), 0, st, pw9, pwd, coefs, per, add_bias_terms,
                      accumulate, b9, wd, dw9, db9, dwd, dbd, N, HW, C);
   HIPCHECK(hipGetLastError());
   return DG_OK;
