@@ -43,9 +43,25 @@ __global__ __launch_bounds__(256) void noise_heads_fwd_kernel(NoiseParams P, con
     if (j >= P.col0[i]) hd = i;
   const int n = P.ncol[hd], jl = j - P.col0[hd];
   const float* W = P.Wh[hd];
+  // The k-order of the chain is pinned (the DEM-critic gradient test is sensitive to the generator's summation order,
+  // DESIGN.md section 2); the launch is bound by load latency, so 16 weights are prefetched a block ahead of the FMAs.
   float acc = 0.f;
-#pragma unroll 8
-  for (int k = 0; k < 1024; ++k) acc = fmaf(sf[k], W[(size_t)k * n + jl], acc);
+  const float* Wj = W + jl;
+  float wa[16], wb[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) wa[u] = Wj[(size_t)u * n];
+  for (int k = 0; k < 1024; k += 32) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wb[u] = Wj[(size_t)(k + 16 + u) * n];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = fmaf(sf[k + u], wa[u], acc);
+    if (k + 32 < 1024) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wa[u] = Wj[(size_t)(k + 32 + u) * n];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = fmaf(sf[k + 16 + u], wb[u], acc);
+  }
   acc += P.bh[hd][jl];
   lin[(size_t)b * 1024 + j] = acc;
   heads[(size_t)b * 1024 + j] = fmaf(acc, P.sh[j], P.th[j]);
