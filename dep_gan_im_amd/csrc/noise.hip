@@ -141,6 +141,7 @@ __global__ __launch_bounds__(1024) void noise_trunk_bwd_kernel(NoiseParams P, No
                                                               float* __restrict__ dl1, float* __restrict__ dl0,
                                                               int B) {
   __shared__ float red[4][1024];
+  __shared__ float sa[1024], sd[1024];
   const int t = threadIdx.x, p = t >> 5, f = t & 31;
   // ---- layer f1: BN + bias grads, dl1 ----
   {
@@ -173,23 +174,36 @@ __global__ __launch_bounds__(1024) void noise_trunk_bwd_kernel(NoiseParams P, No
     __syncthreads();
   }
   // ---- dW1[fi][fo] = sum_{b,p} a0[b,p,fi] * dl1[b,p,fo] ; thread = (fi, fo) ----
+  // (one sample's a0 / dl1 rows are staged in LDS per round: 2048 dependent global loads per thread made this phase
+  // most of the kernel's 237 us; the order of the sum -- b outer, q inner -- is unchanged)
   {
     const int fi = t >> 5, fo = t & 31;
     float acc = 0.f;
-    for (int b = 0; b < B; ++b)
-      for (int q = 0; q < 32; ++q)
-        acc = fmaf(A.a0[(size_t)b * 1024 + q * 32 + fi], dl1[(size_t)b * 1024 + q * 32 + fo], acc);
+    for (int b = 0; b < B; ++b) {
+      __syncthreads();
+      sa[t] = A.a0[(size_t)b * 1024 + t];
+      sd[t] = dl1[(size_t)b * 1024 + t];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 32; ++q) acc = fmaf(sa[q * 32 + fi], sd[q * 32 + fo], acc);
+    }
     G.dW1[fi * 32 + fo] = acc;
   }
   // ---- layer f0 ----
   {
     const float s = P.s0[f], mu = P.mean0[f], rs = P.rstd0[f];
     float sb = 0.f, sg = 0.f, sl = 0.f, sw = 0.f;
+    float w1r[32];                       // this thread's row of W1, loaded once
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w1r[k] = P.W1[f * 32 + k];
     for (int b = 0; b < B; ++b) {
       const size_t o = (size_t)b * 1024 + t;
+      __syncthreads();
+      sd[t] = dl1[o];
+      __syncthreads();
       float da0 = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < 32; ++k) da0 = fmaf(dl1[(size_t)b * 1024 + p * 32 + k], P.W1[f * 32 + k], da0);
+#pragma unroll
+      for (int k = 0; k < 32; ++k) da0 = fmaf(sd[p * 32 + k], w1r[k], da0);
       const float dy = (A.a0[o] > 0.f) ? da0 : 0.f;
       sb += dy;
       sg = fmaf(dy, (A.h0[o] - mu) * rs, sg);
