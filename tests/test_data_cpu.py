@@ -128,3 +128,17 @@ def test_keras_h5_name_mapping():
         weights_from_keras_h5(layers, names)
     with pytest.raises(ImportError):
         g.load_weights("/nonexistent/netG.h5")                               # h5py is not installed in this image
+
+
+def test_split_and_shuffle_host_logic():
+    """dep_gan_im_amd.data.split_and_shuffle is pure indexing: on CPU tensors it must reproduce the oracle's
+    restatement of GT:738-760 (and therefore scikit-learn's split) element for element."""
+    import torch
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=(123, 4, 4, 2)).astype(np.float32)
+    y = rng.normal(size=(123, 4, 4, 1)).astype(np.float32)
+    want = do.split_and_shuffle(x, y, seed_shuffle=11)
+    got = dgdata.split_and_shuffle(torch.from_numpy(x), torch.from_numpy(y), rng=np.random.RandomState(11))
+    assert [tuple(g.shape) for g in got] == [w.shape for w in want]
+    assert all(np.array_equal(g.numpy(), w) for g, w in zip(got, want))
+    assert got[1].shape[0] == 3                        # ceil(0.02 * 123) validation slices
