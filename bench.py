@@ -26,6 +26,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: must be in the environment before the first HIP call of the process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 GFLOP_PER_SLICE = 209.0          # canonical step, SURVEY 8(d)
 PEAK_F32_MFMA = 157.3            # TFLOP/s, MI355X_MICROARCH.md chip table
