@@ -4,10 +4,14 @@
 One "step" = the canonical unit of SURVEY.md 8(d): one critic-Y2 update, one
 critic-DEM update and one generator update (GT:809, 824, 878) on one batch of
 synthetic 256x256x1 slices, fp32, per-GPU batch 32 (BASELINE.json configs[1]).
-Inputs are resident in HBM before the timed region.  With --gpus N > 1 the
-driver launches this file under torch.distributed.run, one rank per GPU; the
-batch is sharded (weak scaling) and each network update all-reduces its flat
-gradient arena over RCCL.
+Inputs are resident in HBM before the timed region.  --gpus N > 1: one rank per
+GPU (weak scaling, per-GPU batch fixed), each network update all-reduces its
+flat gradient arena (+ loss pieces) over RCCL.  Either the driver launches this
+file under torch.distributed.run (WORLD_SIZE set), or -- `python bench.py
+--gpus N` on its own -- this process starts that launcher as a CHILD before
+anything touches HIP, relays rank 0's JSON line and exits with the child's
+status.  --dry-run replaces the GPU engine by a host stand-in and RCCL by gloo
+so that the launcher / rank plumbing can be rehearsed on a machine without GPUs.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline:     MFMA implicit-GEMM convolution class (dominant kernels) --
@@ -74,9 +78,20 @@ def cpu_baseline(sample_batch):
     tr.netD_dem_train([y2, x, z, ep])
     tr.netG_train([x, y2, z])
     dt = time.time() - t0
+    # BASELINE.json configs[0] / BASELINE.md section 3 step 2: generator forward only, batch 4, median of 5
+    x4, _, z4, _ = O.synth_batch(8, 4)
+    O.g_predict(PG, x4, z4)
+    ts = []
+    for _ in range(5):
+        t1 = time.time()
+        O.g_predict(PG, x4, z4)
+        ts.append(time.time() - t1)
+    med = sorted(ts)[2]
     return {"value": round(sample_batch / dt, 4), "unit": "slices/s", "cores": cores, "kind": "port",
             "sample": "one canonical step (critic-Y2 + critic-DEM + G update) at batch %d, 256x256x1 fp32, "
-                      "torch-CPU restatement of the Keras graph (oracle/depgan_oracle.py), %.1f s" % (sample_batch, dt)}
+                      "torch-CPU restatement of the Keras graph (oracle/depgan_oracle.py), %.1f s" % (sample_batch, dt),
+            "g_forward_b4": {"value": round(4 / med, 3), "unit": "slices/s", "ms": round(med * 1e3, 1),
+                             "sample": "BASELINE configs[0]: netG forward only, batch 4, 256x256x1, median of 5"}}
 
 
 def pmc_traffic(batch):
@@ -93,6 +108,99 @@ def pmc_traffic(batch):
     return round(d["igemm_conv_kernel_class"]["hbm_bytes_per_launch"]), "profiles/" + best
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks as a child torch.distributed.run (this
+    process has not touched HIP and never will), relay rank 0's JSON line, exit with the child's status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        sys.stderr.write("bench.py: the ranks finished without a result line\n")
+    return rc
+
+
+class _DryEngine:
+    """Host stand-in for the GPU engine (--dry-run): no arithmetic of the path, only its communication pattern -- a
+    gradient arena with the loss pieces in its tail, summed over the ranks once per update through the same
+    DataParallel hook the library calls."""
+
+    def __init__(self, dp):
+        self.dp, self.device = dp, None
+        self.arenas = {"G": np.zeros(2486145 // 64 + 8, np.float32), "D_y2": np.zeros(1798002 // 64 + 8, np.float32),
+                       "D_dem": np.zeros(1798002 // 64 + 8, np.float32)}
+
+    def update(self, net, rank):
+        a = self.arenas[net]
+        a[:] = rank + 1.0
+        if self.dp is not None:
+            self.dp.allreduce_ptr(a.ctypes.data, a.size)
+        time.sleep(0.002)
+        return float(a[-1])
+
+
+def dry_run(args, world, rank):
+    import torch.distributed as dist
+    dp = None
+    if world > 1:
+        from dep_gan_im_amd.dist import DataParallel
+        dist.init_process_group("gloo")
+        dp = DataParallel()
+    eng = _DryEngine(dp)
+
+    def step():
+        return [eng.update(n, rank) for n in ("D_y2", "D_dem", "G")]
+
+    for _ in range(args.warmup):
+        step()
+    if dp is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = step()
+    if dp is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    want = float(sum(range(1, world + 1)))
+    assert all(abs(g - want) < 1e-6 for g in got), (got, want)     # every rank saw the sum over all ranks
+    if dp is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        B = args.batch
+        print(json.dumps({"metric": "2D slices/sec (G+2D+GP train step), 256x256x1 fp32", "dry_run": True,
+                          "value": round(B * world * args.steps / dt, 3), "unit": "slices/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "none (host stand-in, gloo): rehearsal of the rank plumbing only",
+                          "config": {"workload": "dry run", "per_gpu_batch": B, "global_batch": B * world,
+                                     "parallelism": "dp%d" % world},
+                          "collectives_per_step": 3}), flush=True)
+    if dp is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,16 +209,34 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (32 = BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32)
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: host stand-in engine + gloo (plumbing rehearsal)")
+    ap.add_argument("--n1-value", type=float, default=None,
+                    help="slices/s of the N=1 run, to print scaling_efficiency next to an N>1 value")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run with --nproc-per-node equal to --gpus\n" % (args.gpus, world))
+        return 2
+    if args.dry_run:
+        return dry_run(args, world, rank)
+
+    # The CPU leg runs FIRST, before this process touches the GPU: the GPU phase that follows is then one contiguous
+    # stretch at the end of the run instead of a few seconds hidden in front of ~20 s of host work.
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_sample)
 
     import torch
     import dep_gan_im_amd as dg
     from dep_gan_im_amd.build import build
     build()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda:%d" % local)
     dp = None
@@ -122,9 +248,10 @@ def main():
         dp = DataParallel()
 
     B = args.batch
-    netG = dg.Gen_UNet2D((256, 256, 1), (32, 1), 32, 1, seed=1)
-    netD1 = dg.Dis_C2D_FCN1((256, 256, 1), seed=2)
-    netD2 = dg.Dis_C2D_FCN1((256, 256, 1), seed=3)
+    # deliberately different seeds per rank: build_trainers(dist=dp) must make the replicas identical (rank 0's weights)
+    netG = dg.Gen_UNet2D((256, 256, 1), (32, 1), 32, 1, seed=1 + 100 * rank)
+    netD1 = dg.Dis_C2D_FCN1((256, 256, 1), seed=2 + 100 * rank)
+    netD2 = dg.Dis_C2D_FCN1((256, 256, 1), seed=3 + 100 * rank)
     tr = dg.build_trainers(netG, netD1, netD2, batchSize=B, delta=10.0, lrD=1e-4, lrG=1e-4, IM_TRSH=0.5, dist=dp,
                            device=dev)
     x, y2, z, ep = [torch.from_numpy(a).to(dev) for a in synth(1000 + rank, B)]
@@ -164,6 +291,8 @@ def main():
     conv_bytes = eng.profile_read_bytes(0)
     wg_ms, wg_n, wg_fl = eng.profile_read(1)
     ot_ms, ot_n, _ = eng.profile_read(2)
+    if rank == 0 and os.environ.get("DEPGAN_PROFILE_DUMP"):
+        eng.profile_dump(os.environ["DEPGAN_PROFILE_DUMP"])     # per-launch labelled CSV (layer shapes) of two steps
     eng.profile(False)
     eng.profile_reset()
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -178,8 +307,11 @@ def main():
     gf_ms = (time.perf_counter() - t1) / 5 * 1e3
     gf_tf = 23.513e9 * B / (gf_ms * 1e-3) / 1e12
     # the reference-schedule generator iteration (GT:791-878 steady state): 5 critic-Y2 + 5 critic-DEM
-    # updates, the best-of-10 noise search, one G update = 1013 GFLOP per slice of batch; it consumes 5 batches
+    # updates, the best-of-10 noise search, one G update = 1013 GFLOP per slice of batch; it consumes 5 batches.
+    # Timed both ways: closure by closure (12 host synchronisations) and as ONE library call (depgan_gen_iteration).
     zs = torch.randn(10, B, 32, 1, device=dev)
+    x5, y5 = x.repeat(5, 1, 1, 1), y2.repeat(5, 1, 1, 1)
+    z5, ep5 = z.repeat(5, 1, 1), ep.repeat(5, 1, 1, 1)
 
     def gen_iteration():
         for _ in range(5):
@@ -190,13 +322,19 @@ def main():
         best = min(range(10), key=lambda k: outs[k][0])
         tr.netG_train([x, y2, zs[best]])
 
-    gen_iteration()
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(2):
-        gen_iteration()
-    barrier()
-    gi_ms = (time.perf_counter() - t1) / 2 * 1e3
+    def gen_iteration_fused():
+        tr.gen_iteration((x5, y5, z5, ep5, 5), (x5, y5, z5, ep5, 5), (x, y2, zs))
+
+    gi = {}
+    for name, fn in (("closures", gen_iteration), ("fused", gen_iteration_fused)):
+        fn()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            fn()
+        barrier()
+        gi[name] = (time.perf_counter() - t1) / 2 * 1e3
+    gi_ms = gi["fused"]
     traffic, traffic_src = pmc_traffic(B)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": traffic,
@@ -210,10 +348,12 @@ def main():
                 "ms_per_step": {"igemm_conv": round(conv_ms / 2, 3), "wgrad": round(wg_ms / 2, 3),
                                 "other": round(ot_ms / 2, 3)},
                 "whole_step_frac": round(GFLOP_PER_SLICE * 1e9 * B / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA, 4),
-                "gen_iteration": {"ms": round(gi_ms, 2), "gflop_per_slice_of_batch": 1013.0,
+                "gen_iteration": {"ms": round(gi_ms, 2), "ms_closure_by_closure": round(gi["closures"], 2),
+                                  "host_syncs": 1, "gflop_per_slice_of_batch": 1013.0,
                                   "achieved": round(1013.0e9 * B / (gi_ms * 1e-3) / 1e12, 2),
                                   "epoch_slices_per_s": round(5 * B * world / (gi_ms * 1e-3), 1),
-                                  "unit": "5 critic-Y2 + 5 critic-DEM + best-of-10 + 1 G update (GT:791-878)"},
+                                  "unit": "5 critic-Y2 + 5 critic-DEM + best-of-10 + 1 G update (GT:791-878), one "
+                                          "library call / one host synchronisation"},
                 "g_forward": {"ms": round(gf_ms, 3), "achieved": round(gf_tf, 2),
                               "frac": round(gf_tf / PEAK_F32_MFMA, 4), "slices_per_s": round(B / (gf_ms * 1e-3), 1)}}
 
@@ -226,12 +366,18 @@ def main():
                                        "WGAN-GP), batch %d per GPU, 256x256x1" % B,
                            "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world},
                 "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        if dp is not None:
+            line["collectives"] = {"per_step": 3, "issued": dp.calls,
+                                   "message_floats": [int(eng.arena(n, 2)[1]) + 8 for n in ("D_y2", "D_dem", "G")]}
+        if args.n1_value:
+            line["scaling_efficiency"] = round(value / (world * args.n1_value), 4)
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if dp is not None:
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

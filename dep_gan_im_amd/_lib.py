@@ -18,15 +18,28 @@ EXPORTS = [
     "depgan_profile_reset", "depgan_profile_dump", "depgan_op_conv2d", "depgan_op_conv2d_bwd_data", "depgan_op_conv2d_wgrad",
     "depgan_op_maxpool", "depgan_op_conv2d_stamps", "depgan_uresnet_grads", "depgan_uresnet_step",
     "depgan_uresnet_eval", "depgan_profile_read_bytes", "depgan_g_eval_multi", "depgan_eval_accumulate", "depgan_eval_counts",
-    "depgan_data_prep_scratch_floats", "depgan_data_prep_subject",
+    "depgan_data_prep_scratch_floats", "depgan_data_prep_subject", "depgan_abi_version", "depgan_config_size",
+    "depgan_set_allreduce", "depgan_get_adam_step", "depgan_set_adam_step", "depgan_gen_iteration",
 ]
+
+ABI_VERSION = 2          # DEPGAN_ABI_VERSION of the include/depgan.h this binding was written against
+MAX_MULTI, MAX_CRITIC_STEPS = 32, 256
 
 
 class Config(C.Structure):
-    _fields_ = [("batch", C.c_int), ("height", C.c_int), ("width", C.c_int), ("nicg", C.c_int),
-                ("first_fm", C.c_int), ("im_thresh", C.c_float), ("delta", C.c_float), ("lrD", C.c_float),
-                ("lrG", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-                ("nc_out", C.c_int), ("bf16_weights", C.c_int)]
+    """depgan_config of include/depgan.h, field for field (tests/test_lib_cpu.py parses the header and compares)."""
+    _fields_ = [("struct_size", C.c_int), ("batch", C.c_int), ("height", C.c_int), ("width", C.c_int),
+                ("nicg", C.c_int), ("first_fm", C.c_int), ("im_thresh", C.c_float), ("delta", C.c_float),
+                ("lrD", C.c_float), ("lrG", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("adam_eps", C.c_float), ("nc_out", C.c_int), ("bf16_weights", C.c_int), ("bf16_mfma", C.c_int)]
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.struct_size = C.sizeof(Config)
+
+
+# int fn(void* user, float* dev_ptr, long n, void* hip_stream): the all-reduce hook of depgan_set_allreduce
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p)
 
 
 NET_G, NET_D_Y2, NET_D_DEM = 0, 1, 2
@@ -55,6 +68,19 @@ def load():
     lib = C.CDLL(LIB_PATH)
     fp, vp, ip = C.POINTER(C.c_float), C.c_void_p, C.POINTER(C.c_int)
     lib.depgan_last_error.restype = C.c_char_p
+    lib.depgan_abi_version.argtypes = []
+    lib.depgan_config_size.argtypes = []
+    lib.depgan_config_size.restype = C.c_size_t
+    if lib.depgan_abi_version() != ABI_VERSION or lib.depgan_config_size() != C.sizeof(Config):
+        raise DepganError("libdepgan.so at %s has ABI %d / depgan_config of %d bytes, this binding expects ABI %d / %d "
+                          "bytes: rebuild with `python -m dep_gan_im_amd.build`"
+                          % (LIB_PATH, lib.depgan_abi_version(), lib.depgan_config_size(), ABI_VERSION, C.sizeof(Config)))
+    lib.depgan_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, C.c_int]
+    lib.depgan_get_adam_step.argtypes = [vp, C.c_int]
+    lib.depgan_get_adam_step.restype = C.c_long
+    lib.depgan_set_adam_step.argtypes = [vp, C.c_int, C.c_long]
+    lib.depgan_gen_iteration.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_long, vp, vp, vp,
+                                         C.c_int, fp, ip]
     lib.depgan_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.depgan_destroy.argtypes = [vp]
     lib.depgan_destroy.restype = None

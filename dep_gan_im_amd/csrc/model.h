@@ -146,6 +146,15 @@ struct depgan_ctx {
   float* coefs = nullptr;          // [4] per-group upstream coefficients
   float *norms = nullptr, *gp = nullptr;
 
+  // ---- data parallelism + deferred scalars ----
+  depgan_allreduce_fn ar_fn = nullptr;   // all-reduce (sum) hook, enqueued on the stream (include/depgan.h)
+  void* ar_user = nullptr;
+  int world = 1;
+  float* host_stats = nullptr;     // pinned: un-normalised loss pieces of the updates of one call, fetched asynchronously
+  int* best_dev = nullptr;         // arg-min of the best-of-k search (device) and its pinned host copy
+  int* best_host = nullptr;
+  float* z_best = nullptr;         // [B][32] the chosen noise, gathered on the device
+
   // ---- shared scratch ----
   float* part = nullptr;           // wgrad slabs
   size_t partFloats = 0;
@@ -210,7 +219,7 @@ struct ColSum {
 };
 int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, int Cin, int Cout, const float* scale,
                float* out, float* raw, int accumulate, int oi, const ColSum* cs = nullptr);
-int net_adam(depgan_ctx* c, Net& n);
+int net_adam(depgan_ctx* c, Net& n, float gscale = 1.0f);
 int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u);
 int refresh_generator(depgan_ctx* c);
 int refresh_generator_bn(depgan_ctx* c);  // phase-0 BN affines only (after the moving statistics moved)

@@ -63,9 +63,12 @@ int talloc(depgan_ctx* c, Tn* t, int N, int H, int W, int C) {
   t->C = C;
   return dmalloc(c, &t->p, (size_t)N * H * W * C);
 }
+// floats behind the gradients in every GRADS arena: the update's un-normalised loss pieces travel in the same
+// all-reduce message as the gradient (nTrain is a multiple of 4, so the tail is 16-byte aligned)
+#define STATS_TAIL 8
 static int net_alloc(depgan_ctx* c, Net* n) {
   DGCHECK(dmalloc(c, &n->P, n->nTrain));
-  DGCHECK(dmalloc(c, &n->G, n->nTrain));
+  DGCHECK(dmalloc(c, &n->G, n->nTrain + STATS_TAIL));   // tail: un-normalised loss pieces, reduced with the gradient
   DGCHECK(dmalloc(c, &n->M, n->nTrain));
   DGCHECK(dmalloc(c, &n->V, n->nTrain));
   DGCHECK(dmalloc(c, &n->NT, n->nNon));
@@ -886,20 +889,21 @@ static int d_backward_chain(depgan_ctx* c, DNet& D, long s0, int N, const float*
   return DG_OK;
 }
 
-int net_adam(depgan_ctx* c, Net& n) {
+int net_adam(depgan_ctx* c, Net& n, float gscale) {
   n.adam_t += 1;
   const double b1 = c->cfg.beta1, b2 = c->cfg.beta2;
   const double t = (double)n.adam_t;
   const double lr_t = n.lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
   ProfScope ps(c, 2, 0.0);
-  return dg_adam(n.P, n.G, n.M, n.V, n.nTrain, (float)lr_t, (float)b1, (float)b2, c->cfg.adam_eps, c->st);
+  return dg_adam(n.P, n.G, n.M, n.V, n.nTrain, (float)lr_t, (float)b1, (float)b2, c->cfg.adam_eps, gscale, c->st);
 }
 
 // ---------------------------------------------------------------------------
 // closures
 // ---------------------------------------------------------------------------
-static int critic_grads(depgan_ctx* c, int which, const float* y2, const float* x, const float* z, const float* ep,
-                        float out[2]) {
+// Enqueues one critic evaluation + its gradients (GT:540-549 / 562-568).  Leaves d loss / d theta_D in the GRADS arena
+// and the un-normalised loss pieces [sum D(real), sum D(fake), sum (norm-1)^2, B] in its tail.  No host synchronisation.
+static int critic_enqueue(depgan_ctx* c, int which, const float* y2, const float* x, const float* z, const float* ep) {
   if (c->cfg.nc_out != 1) { dg_set_error("the WGAN-GP closures need nc_out == 1"); return DG_ERR_ARG; }
   DNet& D = c->d[which];
   const int B = c->cfg.batch, H0 = c->cfg.height, W0 = c->cfg.width;
@@ -915,7 +919,7 @@ static int critic_grads(depgan_ctx* c, int which, const float* y2, const float* 
   float* u0 = c->d_in + 2 * B * HW0;
   {
     ProfScope ps(c, 2, 0.0);
-    DGCHECK(dg_gp_u0(c->g0, u0, c->norms, c->gp, c->cfg.delta, B, HW0, c->scratch, c->st));
+    DGCHECK(dg_gp_u0(c->g0, u0, c->norms, nullptr, c->cfg.delta, B, HW0, c->scratch, c->st));
   }
   // u-forward through the masks of the mixed pass, overwriting the mixed slots
   for (int l = 0; l < 11; ++l) {
@@ -961,25 +965,16 @@ static int critic_grads(depgan_ctx* c, int which, const float* y2, const float* 
                                  c->scratch, 2 * B, HW, 256, c->st));
     DGCHECK(dg_critic_tail_wgrad(c->d_act[10].p + (size_t)2 * B * c->d_act[10].per_sample(), D.w9, D.b9, D.wd,
                                  c->coefs + 2, B, 0, 1, D.dw9, D.db9, D.dwd, D.dbd, c->scratch, B, HW, 256, c->st));
-    DGCHECK(dg_mean_groups(c->d_out, c->scal, 2, B, c->st));
+    DGCHECK(dg_critic_stats(c->d_out, c->norms, D.net.G + D.net.nTrain, B, c->st));
   }
-  float h[3];
-  HIPCHECK(hipMemcpyAsync(h, c->scal, 2 * sizeof(float), hipMemcpyDeviceToHost, c->st));
-  HIPCHECK(hipMemcpyAsync(h + 2, c->gp, sizeof(float), hipMemcpyDeviceToHost, c->st));
-  HIPCHECK(hipStreamSynchronize(c->st));
-  out[0] = h[0];
-  out[1] = h[1];
-  c->last_sums[0] = h[0] * B;
-  c->last_sums[1] = h[1] * B;
-  c->last_sums[2] = h[2] * B;
-  c->last_sums[3] = (float)B;
   return DG_OK;
 }
 
-// device part of one generator-loss evaluation; leaves [mean D_y2(fake), mean D_dem(attr), -, -, sum|attr-real_dem|,
-// sum wr, sum wf, sum wr*wf] in scal_dev[0..8)
+// device part of one generator-loss evaluation; leaves the 8 un-normalised pieces [sum D_y2(fake), sum D_dem(attr),
+// sum|attr-real_dem|, sum wr, sum wf, sum wr*wf, B, B*H*W] in stats_dev[0..8).  train: also d loss / d theta_G in the
+// generator's GRADS arena.  No host synchronisation.
 static int g_eval_enqueue(depgan_ctx* c, const float* x, const float* y2, const float* z, bool train,
-                          float* scal_dev) {
+                          float* stats_dev) {
   const int B = c->cfg.batch, H0 = c->cfg.height, W0 = c->cfg.width;
   const long HW0 = (long)H0 * W0, P = (long)B * HW0;
   DGCHECK(g_forward(c, x, z, B, train));
@@ -991,8 +986,8 @@ static int g_eval_enqueue(depgan_ctx* c, const float* x, const float* y2, const 
   DGCHECK(d_forward(c, c->d[1], c->attr.p, B, B));
   {
     ProfScope ps(c, 2, 0.0);
-    DGCHECK(dg_mean_groups(c->d_out, scal_dev, 2, B, c->st));
-    DGCHECK(dg_gloss_sums(x, c->cfg.nicg, y2, c->attr.p, c->cfg.im_thresh, scal_dev + 4, P, c->scratch, c->st));
+    DGCHECK(dg_sum_groups_consts(c->d_out, stats_dev, 2, B, 6, (float)B, (float)P, c->st));
+    DGCHECK(dg_gloss_sums(x, c->cfg.nicg, y2, c->attr.p, c->cfg.im_thresh, stats_dev + 2, P, c->scratch, c->st));
   }
   if (train) {
     // d loss / d attr needs dD/dimage of both critics with upstream 1 per sample (GT:592)
@@ -1007,39 +1002,77 @@ static int g_eval_enqueue(depgan_ctx* c, const float* x, const float* y2, const 
   return DG_OK;
 }
 
-// host part: the six reported scalars and the un-normalised pieces from the 8 device values
-static void g_eval_finish(const depgan_ctx* c, const float h[8], float out[6], float sums[8]) {
-  const int B = c->cfg.batch;
-  const long P = (long)B * c->cfg.height * c->cfg.width;
-  const double lf = h[0], lfd = h[1], sabs = h[4], swr = h[5], swf = h[6], sin_ = h[7];
-  const double m1 = 100.0 * sabs / (double)P;                        // GT:576
-  const double dv = swr / 1000.0 - swf / 1000.0;
-  const double m3 = 100.0 * dv * dv;                                 // GT:587-589
-  const double dice = (2.0 * sin_ + 1e-7) / (swr + swf + 1e-7);      // GT:153-157
-  const double m4 = 1.0 - dice;                                      // GT:583
-  out[0] = (float)(-lf - lfd + m1 + m3 + m4);                        // GT:592
+// host part: the six reported scalars from the 8 un-normalised pieces (GT:576-592).  Kept statement for statement
+// identical to g_total_loss_dev() in ops.hip (the device's arg-min must be the host's).
+static void g_loss_from_sums(const float s[8], float out[6]) {
+#pragma clang fp contract(off)
+  const double n = s[6], npix = s[7];
+  const double lf = (double)s[0] / n, lfd = (double)s[1] / n;
+  const double m1 = 100.0 * (double)s[2] / npix;                                            // GT:576
+  const double dv = (double)s[3] / 1000.0 - (double)s[4] / 1000.0;
+  const double m3 = 100.0 * dv * dv;                                                        // GT:587-589
+  const double dice = (2.0 * (double)s[5] + 1e-7) / ((double)s[3] + (double)s[4] + 1e-7);  // GT:153-157
+  const double m4 = 1.0 - dice;                                                             // GT:583
+  out[0] = (float)(-lf - lfd + m1 + m3 + m4);                                               // GT:592
   out[1] = (float)lf;
   out[2] = (float)lfd;
   out[3] = (float)m1;
   out[4] = (float)m3;
   out[5] = (float)m4;
-  sums[0] = (float)(lf * B);
-  sums[1] = (float)(lfd * B);
-  sums[2] = (float)sabs;
-  sums[3] = (float)swr;
-  sums[4] = (float)swf;
-  sums[5] = (float)sin_;
-  sums[6] = (float)B;
-  sums[7] = (float)P;
+}
+static void critic_from_sums(const float s[4], float out[2]) {   // GT:540-541
+  out[0] = (float)((double)s[0] / (double)s[3]);
+  out[1] = (float)((double)s[1] / (double)s[3]);
 }
 
-static int g_eval_impl(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6], bool train) {
-  if (c->cfg.nc_out != 1) { dg_set_error("the WGAN-GP closures need nc_out == 1"); return DG_ERR_ARG; }
-  DGCHECK(g_eval_enqueue(c, x, y2, z, train, c->scal));
-  float h[8];
-  HIPCHECK(hipMemcpyAsync(h, c->scal, 8 * sizeof(float), hipMemcpyDeviceToHost, c->st));
+// ---- update plumbing: [all-reduce] -> async fetch of the loss pieces -> Adam -> derived state ----
+#define HOST_STATS_FLOATS (8 * (DEPGAN_MAX_CRITIC_STEPS + DEPGAN_MAX_MULTI + 2))
+
+static int dp_reduce(depgan_ctx* c, float* dev, long n) {
+  if (!c->ar_fn) return DG_OK;
+  ProfScope ps(c, 2, 0.0, "all-reduce");
+  const int rc = c->ar_fn(c->ar_user, dev, n, (void*)c->st);
+  if (rc != 0) {
+    dg_set_error("the all-reduce hook failed with status %d", rc);
+    return DG_ERR_HIP;
+  }
+  return DG_OK;
+}
+static int fetch_async(depgan_ctx* c, const float* dev, int n, int slot_floats) {
+  HIPCHECK(hipMemcpyAsync(c->host_stats + slot_floats, dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->st));
+  return DG_OK;
+}
+static int refresh_net(depgan_ctx* c, int net) { return depgan_weights_changed(c, net); }
+// after grads + loss pieces are in the GRADS arena of `net`: reduce across ranks, fetch the pieces into host slot, update
+static int finish_update(depgan_ctx* c, int net, Net& n, int nstats, int slot_floats, bool update) {
+  if (update) DGCHECK(dp_reduce(c, n.G, (long)n.nTrain + STATS_TAIL));
+  DGCHECK(fetch_async(c, n.G + n.nTrain, nstats, slot_floats));
+  if (!update) return DG_OK;
+  DGCHECK(net_adam(c, n, c->ar_fn ? 1.0f / (float)c->world : 1.0f));
+  return refresh_net(c, net);
+}
+
+static int critic_impl(depgan_ctx* c, int net, const float* y2, const float* x, const float* z, const float* ep,
+                       float out[2], bool update) {
+  if (net != DEPGAN_NET_D_Y2 && net != DEPGAN_NET_D_DEM) { dg_set_error("not a critic id"); return DG_ERR_ARG; }
+  DGCHECK(critic_enqueue(c, net - 1, y2, x, z, ep));
+  DGCHECK(finish_update(c, net, c->d[net - 1].net, 4, 0, update));
   HIPCHECK(hipStreamSynchronize(c->st));
-  g_eval_finish(c, h, out, c->last_sums);
+  critic_from_sums(c->host_stats, out);
+  memcpy(c->last_sums, c->host_stats, 4 * sizeof(float));
+  return DG_OK;
+}
+
+static int g_impl(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6], bool train,
+                  bool update) {
+  if (c->cfg.nc_out != 1) { dg_set_error("the WGAN-GP closures need nc_out == 1"); return DG_ERR_ARG; }
+  float* stats = c->g.G + c->g.nTrain;
+  DGCHECK(g_eval_enqueue(c, x, y2, z, train, stats));
+  if (!train) DGCHECK(dp_reduce(c, stats, 8));   // netG_no_update reports global scalars
+  DGCHECK(finish_update(c, DEPGAN_NET_G, c->g, 8, 0, update));
+  HIPCHECK(hipStreamSynchronize(c->st));
+  g_loss_from_sums(c->host_stats, out);
+  memcpy(c->last_sums, c->host_stats, 8 * sizeof(float));
   return DG_OK;
 }
 
@@ -1058,8 +1091,21 @@ extern "C" {
 
 const char* depgan_last_error(void) { return dg_get_error(); }
 
+int depgan_abi_version(void) { return DEPGAN_ABI_VERSION; }
+size_t depgan_config_size(void) { return sizeof(depgan_config); }
+
 int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
   if (!cfg || !out) { dg_set_error("depgan_create: null argument"); return DG_ERR_ARG; }
+  if (cfg->struct_size != (int)sizeof(depgan_config)) {
+    dg_set_error("depgan_create: depgan_config.struct_size is %d, this library (ABI %d) expects %d -- the caller was "
+                 "built against another include/depgan.h", cfg->struct_size, DEPGAN_ABI_VERSION,
+                 (int)sizeof(depgan_config));
+    return DG_ERR_ARG;
+  }
+  if (cfg->bf16_mfma && !cfg->bf16_weights) {
+    dg_set_error("depgan_create: bf16_mfma needs bf16_weights = 1");
+    return DG_ERR_ARG;
+  }
   if (cfg->batch < 1 || cfg->height % 16 || cfg->width % 16 || cfg->height < 16 || cfg->width < 16 || cfg->nicg < 1 ||
       cfg->nicg > 2) {
     dg_set_error("depgan_create: need batch >= 1, height/width multiples of 16, nicg in {1,2}");
@@ -1106,6 +1152,17 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
   if (rc == DG_OK) rc = dmalloc(c, &c->scratch, (size_t)(1 << 20) + (size_t)cfg->batch * 20000);
   if (rc == DG_OK) rc = dmalloc(c, &c->scal, 16);
   if (rc == DG_OK) rc = dmalloc(c, &c->scal_multi, 8 * DEPGAN_MAX_MULTI);
+  if (rc == DG_OK) rc = dmalloc(c, &c->z_best, (size_t)cfg->batch * 32);
+  if (rc == DG_OK) {
+    float* p = nullptr;
+    rc = dmalloc(c, &p, 4);
+    c->best_dev = reinterpret_cast<int*>(p);
+  }
+  if (rc == DG_OK && hipHostMalloc((void**)&c->host_stats, (HOST_STATS_FLOATS + 4) * sizeof(float)) != hipSuccess) {
+    dg_set_error("depgan_create: hipHostMalloc failed");
+    rc = DG_ERR_HIP;
+  }
+  if (rc == DG_OK) c->best_host = reinterpret_cast<int*>(c->host_stats + HOST_STATS_FLOATS);
   if (rc != DG_OK) {
     depgan_destroy(c);
     return rc;
@@ -1118,6 +1175,7 @@ void depgan_destroy(depgan_ctx* c) {
   if (!c) return;
   hipDeviceSynchronize();
   for (void* p : c->allocs) hipFree(p);
+  if (c->host_stats) hipHostFree(c->host_stats);
   for (ProfRec& r : c->recs) {
     hipEventDestroy(r.a);
     hipEventDestroy(r.b);
@@ -1127,6 +1185,19 @@ void depgan_destroy(depgan_ctx* c) {
 
 int depgan_set_stream(depgan_ctx* c, void* s) {
   c->st = (hipStream_t)s;
+  return DG_OK;
+}
+
+int depgan_set_allreduce(depgan_ctx* c, depgan_allreduce_fn fn, void* user, int world) {
+  if (fn && world >= 1) {   // world == 1 keeps the hook (a one-rank group: rehearses the collective path exactly)
+    c->ar_fn = fn;
+    c->ar_user = user;
+    c->world = world;
+  } else {
+    c->ar_fn = nullptr;
+    c->ar_user = nullptr;
+    c->world = 1;
+  }
   return DG_OK;
 }
 
@@ -1197,8 +1268,7 @@ int depgan_d_forward(depgan_ctx* c, int net, const float* img, float* out, int n
 
 int depgan_critic_grads(depgan_ctx* c, int net, const float* y2, const float* x, const float* z, const float* ep,
                         float out[2]) {
-  if (net != DEPGAN_NET_D_Y2 && net != DEPGAN_NET_D_DEM) { dg_set_error("critic_grads: not a critic id"); return DG_ERR_ARG; }
-  return critic_grads(c, net - 1, y2, x, z, ep, out);
+  return critic_impl(c, net, y2, x, z, ep, out, false);
 }
 
 int depgan_apply_adam(depgan_ctx* c, int net) {
@@ -1208,34 +1278,93 @@ int depgan_apply_adam(depgan_ctx* c, int net) {
   return depgan_weights_changed(c, net);
 }
 
+long depgan_get_adam_step(depgan_ctx* c, int net) {
+  Net* n = pick_net(c, net);
+  return n ? n->adam_t : -1;
+}
+int depgan_set_adam_step(depgan_ctx* c, int net, long t) {
+  Net* n = pick_net(c, net);
+  if (!n || t < 0) { dg_set_error("set_adam_step: bad argument"); return DG_ERR_ARG; }
+  n->adam_t = t;
+  return DG_OK;
+}
+
 int depgan_critic_step(depgan_ctx* c, int net, const float* y2, const float* x, const float* z, const float* ep,
                        float out[2]) {
-  DGCHECK(depgan_critic_grads(c, net, y2, x, z, ep, out));
-  return depgan_apply_adam(c, net);
+  return critic_impl(c, net, y2, x, z, ep, out, true);
 }
 
 int depgan_g_eval(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6]) {
-  return g_eval_impl(c, x, y2, z, out, false);
+  return g_impl(c, x, y2, z, out, false, false);
+}
+// k evaluations into scal_multi (k x 8 pieces), reduced across ranks when a hook is set.  No host synchronisation.
+static int g_eval_multi_enqueue(depgan_ctx* c, const float* x, const float* y2, const float* z_all, int k) {
+  if (c->cfg.nc_out != 1) { dg_set_error("the WGAN-GP closures need nc_out == 1"); return DG_ERR_ARG; }
+  if (k < 1 || k > DEPGAN_MAX_MULTI) { dg_set_error("best-of-k: k must be in [1, %d]", DEPGAN_MAX_MULTI); return DG_ERR_ARG; }
+  const size_t zstride = (size_t)c->cfg.batch * 32;
+  for (int i = 0; i < k; ++i) DGCHECK(g_eval_enqueue(c, x, y2, z_all + i * zstride, false, c->scal_multi + 8 * i));
+  return dp_reduce(c, c->scal_multi, 8L * k);
 }
 int depgan_g_eval_multi(depgan_ctx* c, const float* x, const float* y2, const float* z_all, int k, float* out,
                         float* sums) {
-  if (c->cfg.nc_out != 1) { dg_set_error("the WGAN-GP closures need nc_out == 1"); return DG_ERR_ARG; }
-  if (k < 1 || k > DEPGAN_MAX_MULTI) { dg_set_error("g_eval_multi: k must be in [1, %d]", DEPGAN_MAX_MULTI); return DG_ERR_ARG; }
-  const size_t zstride = (size_t)c->cfg.batch * 32;
-  for (int i = 0; i < k; ++i) DGCHECK(g_eval_enqueue(c, x, y2, z_all + i * zstride, false, c->scal_multi + 8 * i));
-  float h[8 * DEPGAN_MAX_MULTI];
-  HIPCHECK(hipMemcpyAsync(h, c->scal_multi, (size_t)8 * k * sizeof(float), hipMemcpyDeviceToHost, c->st));
+  DGCHECK(g_eval_multi_enqueue(c, x, y2, z_all, k));
+  DGCHECK(fetch_async(c, c->scal_multi, 8 * k, 0));
   HIPCHECK(hipStreamSynchronize(c->st));      // the only host synchronisation of the k evaluations
-  float tmp[8];
-  for (int i = 0; i < k; ++i) g_eval_finish(c, h + 8 * i, out + 6 * i, sums ? sums + 8 * i : tmp);
+  for (int i = 0; i < k; ++i) {
+    g_loss_from_sums(c->host_stats + 8 * i, out + 6 * i);
+    if (sums) memcpy(sums + 8 * i, c->host_stats + 8 * i, 8 * sizeof(float));
+  }
   return DG_OK;
 }
 int depgan_g_grads(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6]) {
-  return g_eval_impl(c, x, y2, z, out, true);
+  return g_impl(c, x, y2, z, out, true, false);
 }
 int depgan_g_step(depgan_ctx* c, const float* x, const float* y2, const float* z, float out[6]) {
-  DGCHECK(g_eval_impl(c, x, y2, z, out, true));
-  return depgan_apply_adam(c, DEPGAN_NET_G);
+  return g_impl(c, x, y2, z, out, true, true);
+}
+
+int depgan_gen_iteration(depgan_ctx* c, const float* x_y2, const float* y2_y2, const float* z_y2, const float* ep_y2,
+                         int n_y2, const float* x_dem, const float* y2_dem, const float* z_dem, const float* ep_dem,
+                         int n_dem, long batch_stride, const float* x_gen, const float* y2_gen, const float* z_gen, int k,
+                         float* out_host, int* best_host) {
+  if (c->cfg.nc_out != 1) { dg_set_error("the WGAN-GP closures need nc_out == 1"); return DG_ERR_ARG; }
+  if (n_y2 < 0 || n_dem < 0 || n_y2 + n_dem > DEPGAN_MAX_CRITIC_STEPS || k < 1 || k > DEPGAN_MAX_MULTI || !out_host ||
+      !best_host || !x_gen || !y2_gen || !z_gen || batch_stride < 0) {
+    dg_set_error("gen_iteration: need 0 <= n_y2 + n_dem <= %d, 1 <= k <= %d and non-null generator inputs",
+                 DEPGAN_MAX_CRITIC_STEPS, DEPGAN_MAX_MULTI);
+    return DG_ERR_ARG;
+  }
+  const int B = c->cfg.batch;
+  const long xs = batch_stride * c->cfg.height * c->cfg.width * c->cfg.nicg;
+  const long ys = batch_stride * c->cfg.height * c->cfg.width;
+  int slot = 0;
+  for (int j = 0; j < n_y2; ++j, slot += 4) {                                           // GT:802-814
+    DGCHECK(critic_enqueue(c, 0, y2_y2 + j * ys, x_y2 + j * xs, z_y2 + (size_t)j * B * 32, ep_y2 + (size_t)j * B));
+    DGCHECK(finish_update(c, DEPGAN_NET_D_Y2, c->d[0].net, 4, slot, true));
+  }
+  for (int j = 0; j < n_dem; ++j, slot += 4) {                                          // GT:817-829
+    DGCHECK(critic_enqueue(c, 1, y2_dem + j * ys, x_dem + j * xs, z_dem + (size_t)j * B * 32, ep_dem + (size_t)j * B));
+    DGCHECK(finish_update(c, DEPGAN_NET_D_DEM, c->d[1].net, 4, slot, true));
+  }
+  DGCHECK(g_eval_multi_enqueue(c, x_gen, y2_gen, z_gen, k));                            // GT:868-874
+  DGCHECK(fetch_async(c, c->scal_multi, 8 * k, slot));
+  const int slot_k = slot;
+  slot += 8 * k;
+  {
+    ProfScope ps(c, 2, 0.0, "best noise");
+    DGCHECK(dg_best_noise(c->scal_multi, k, z_gen, (long)B * 32, c->best_dev, c->z_best, c->st));   // GT:875-876
+  }
+  HIPCHECK(hipMemcpyAsync(c->best_host, c->best_dev, sizeof(int), hipMemcpyDeviceToHost, c->st));
+  DGCHECK(g_eval_enqueue(c, x_gen, y2_gen, c->z_best, true, c->g.G + c->g.nTrain));     // GT:878
+  DGCHECK(finish_update(c, DEPGAN_NET_G, c->g, 8, slot, true));
+  HIPCHECK(hipStreamSynchronize(c->st));       // the one host synchronisation of the generator iteration
+  float* o = out_host;
+  for (int j = 0; j < n_y2 + n_dem; ++j, o += 2) critic_from_sums(c->host_stats + 4 * j, o);
+  for (int i = 0; i < k; ++i, o += 6) g_loss_from_sums(c->host_stats + slot_k + 8 * i, o);
+  g_loss_from_sums(c->host_stats + slot, o);
+  memcpy(c->last_sums, c->host_stats + slot, 8 * sizeof(float));
+  *best_host = *c->best_host;
+  return DG_OK;
 }
 
 int depgan_last_sums(depgan_ctx* c, float out[8]) {

@@ -88,11 +88,21 @@ int dg_bn_gamma_grad(const float* W, const float* dWraw, int K, int Cout, int oi
                      const float* mean, const float* rstd, const float* S, float* dgamma, hipStream_t st);
 
 // Keras Adam over a flat arena (App. B.6).  lr_t computed on the host.
+// gscale multiplies the gradient first (1/world after a summing all-reduce; 1 otherwise)
 int dg_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
-            hipStream_t st);
+            float gscale, hipStream_t st);
 
 int dg_scale_copy(const float* in, float* out, size_t n, float s, hipStream_t st);
 int dg_mean_groups(const float* in, float* out, int groups, int per, hipStream_t st);
+// un-normalised loss pieces of one critic evaluation: out = [sum in[0..B), sum in[B..2B), sum_b (norms[b]-1)^2, B]
+int dg_critic_stats(const float* d_out, const float* norms, float* out, int B, hipStream_t st);
+// out[g] = sum of group g (g < groups); out[coff] = c0, out[coff+1] = c1
+int dg_sum_groups_consts(const float* in, float* out, int groups, int per, int coff, float c0, float c1, hipStream_t st);
+// best-of-k noise search on the device (GT:868-877): stats = k x 8 un-normalised pieces
+// [sum D_y2(fake), sum D_dem(attr), sum|attr-real_dem|, sum wr, sum wf, sum wr*wf, n, n*H*W]; forms the k total losses
+// with the host's algebra (double, rounded to float), takes the FIRST minimum, writes its index to *best and copies
+// z_all[best] (zfloats values) to z_out
+int dg_best_noise(const float* stats, int k, const float* z_all, long zfloats, int* best, float* z_out, hipStream_t st);
 
 // dst[i] = mask[i] ? float(bf16_rne(src[i])) : src[i]      (bf16-weights mode: master -> compute copy)
 int dg_round_bf16_masked(const float* src, const unsigned char* mask, float* dst, size_t n, hipStream_t st);

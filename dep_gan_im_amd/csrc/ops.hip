@@ -619,8 +619,10 @@ int dg_gp_u0(const float* g0, float* u0, float* norms, float* gp_out, float delt
   HIPCHECK(hipGetLastError());
   hipLaunchKernelGGL(gp_scale_kernel, dim3(B, GP_SPLIT), dim3(256), 0, st, g0, u0, scratch, norms, delta, B, HW);
   HIPCHECK(hipGetLastError());
-  hipLaunchKernelGGL(gp_value_kernel, dim3(1), dim3(256), 0, st, norms, gp_out, B);
-  HIPCHECK(hipGetLastError());
+  if (gp_out) {   // the step drivers take sum (norm-1)^2 from dg_critic_stats instead
+    hipLaunchKernelGGL(gp_value_kernel, dim3(1), dim3(256), 0, st, norms, gp_out, B);
+    HIPCHECK(hipGetLastError());
+  }
   return DG_OK;
 }
 
@@ -794,9 +796,9 @@ int dg_bn_gamma_grad(const float* W, const float* dWraw, int K, int Cout, int oi
 // Adam
 // ---------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps) {
+                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, float gscale) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
+    const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
     m[i] = mi;
@@ -805,8 +807,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 int dg_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
-            hipStream_t st) {
-  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 2048)), dim3(256), 0, st, p, g, m, v, n, lr_t, b1, b2, eps);
+            float gscale, hipStream_t st) {
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 2048)), dim3(256), 0, st, p, g, m, v, n, lr_t, b1, b2, eps, gscale);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
@@ -831,6 +833,92 @@ __global__ void mean_groups_kernel(const float* __restrict__ in, float* __restri
 }
 int dg_mean_groups(const float* in, float* out, int groups, int per, hipStream_t st) {
   hipLaunchKernelGGL(mean_groups_kernel, dim3(groups), dim3(256), 0, st, in, out, per);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
+// un-normalised pieces of one critic evaluation (one block): [sum D(real), sum D(fake), sum (norm-1)^2, B]
+__global__ void critic_stats_kernel(const float* __restrict__ d_out, const float* __restrict__ norms,
+                                    float* __restrict__ out, int B) {
+  __shared__ float sh4[4];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    a0 += d_out[i];
+    a1 += d_out[B + i];
+    const float d = norms[i] - 1.0f;
+    a2 += d * d;
+  }
+  a0 = block_sum(a0, sh4);
+  a1 = block_sum(a1, sh4);
+  a2 = block_sum(a2, sh4);
+  if (threadIdx.x == 0) {
+    out[0] = a0;
+    out[1] = a1;
+    out[2] = a2;
+    out[3] = (float)B;
+  }
+}
+int dg_critic_stats(const float* d_out, const float* norms, float* out, int B, hipStream_t st) {
+  hipLaunchKernelGGL(critic_stats_kernel, dim3(1), dim3(256), 0, st, d_out, norms, out, B);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
+__global__ void sum_groups_consts_kernel(const float* __restrict__ in, float* __restrict__ out, int per, int coff,
+                                         float c0, float c1) {
+  __shared__ float sh4[4];
+  const int g = blockIdx.x;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < per; i += blockDim.x) acc += in[(size_t)g * per + i];
+  acc = block_sum(acc, sh4);
+  if (threadIdx.x == 0) {
+    out[g] = acc;
+    if (g == 0) {
+      out[coff] = c0;
+      out[coff + 1] = c1;
+    }
+  }
+}
+int dg_sum_groups_consts(const float* in, float* out, int groups, int per, int coff, float c0, float c1,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(sum_groups_consts_kernel, dim3(groups), dim3(256), 0, st, in, out, per, coff, c0, c1);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
+// The generator's total loss from its 8 un-normalised pieces: the SAME statement sequence as g_loss_from_sums() in
+// model.hip (host), double arithmetic without contraction, rounded to float -- so the device's arg-min is the host's.
+__device__ float g_total_loss_dev(const float* s) {
+#pragma clang fp contract(off)
+  const double n = s[6], npix = s[7];
+  const double lf = (double)s[0] / n, lfd = (double)s[1] / n;
+  const double m1 = 100.0 * (double)s[2] / npix;
+  const double dv = (double)s[3] / 1000.0 - (double)s[4] / 1000.0;
+  const double m3 = 100.0 * dv * dv;
+  const double dice = (2.0 * (double)s[5] + 1e-7) / ((double)s[3] + (double)s[4] + 1e-7);
+  const double m4 = 1.0 - dice;
+  return (float)(-lf - lfd + m1 + m3 + m4);
+}
+__global__ void best_noise_kernel(const float* __restrict__ stats, int k, const float* __restrict__ z_all, long zfloats,
+                                  int* __restrict__ best, float* __restrict__ z_out) {
+  __shared__ int sbest;
+  if (threadIdx.x == 0) {
+    int bi = 0;
+    float bv = g_total_loss_dev(stats);
+    for (int i = 1; i < k; ++i) {
+      const float v = g_total_loss_dev(stats + 8 * i);
+      if (v < bv) { bv = v; bi = i; }     // first minimum, like np.argmin; NaN never wins (as in NumPy only if first)
+    }
+    sbest = bi;
+    *best = bi;
+  }
+  __syncthreads();
+  const float* src = z_all + (size_t)sbest * zfloats;
+  for (long i = threadIdx.x; i < zfloats; i += blockDim.x) z_out[i] = src[i];
+}
+int dg_best_noise(const float* stats, int k, const float* z_all, long zfloats, int* best, float* z_out,
+                  hipStream_t st) {
+  hipLaunchKernelGGL(best_noise_kernel, dim3(1), dim3(256), 0, st, stats, k, z_all, zfloats, best, z_out);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }

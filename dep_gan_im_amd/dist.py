@@ -1,17 +1,29 @@
 """Batch-sharded data parallelism for the train step.
 
 The reference is single-GPU (GT:13).  Here every rank holds full replicas of G
-and both critics and a shard of the batch; per network update there is exactly
-one collective on the flat fp32 gradient arena (RCCL all-reduce over xGMI when
-the process group backend is "nccl"; gloo on CPU in the tests), followed by a
-tiny all-reduce of un-normalised loss pieces so that every rank reports the
-same global scalars and -- because M3/M4 (GT:583-589) are non-linear in the
-batch-global counts -- the same best-of-k noise choice (GT:868-877).
+and both critics and a shard of the batch.  libdepgan stays free of any
+communication dependency: it calls ONE hook (depgan_set_allreduce) that
+all-reduces device floats in place, enqueued on the engine's HIP stream; this
+module implements that hook with torch.distributed (RCCL over xGMI when the
+process group backend is "nccl"; gloo on CPU in the tests).  Per network update
+there is exactly one collective: the flat fp32 gradient arena with the
+update's un-normalised loss pieces riding in its tail, summed; Adam divides the
+gradient by the world size (losses are batch means, GT:540-545, 576), and every
+rank forms the same GLOBAL scalars from the summed pieces -- M3/M4 (GT:583-589)
+are non-linear in the batch-global counts -- hence the same best-of-k noise
+choice (GT:868-877), which the library takes on the device.  Nothing here
+synchronises the host: a whole generator iteration (depgan_gen_iteration) is
+one enqueue with its collectives in stream order.
 """
 from __future__ import annotations
 
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
+
+from ._lib import ARENA_ADAM_M, ARENA_ADAM_V, ARENA_NONTRAINABLE, ARENA_PARAMS
 
 
 class _DevArray:
@@ -29,7 +41,8 @@ def combine_critic_sums(s):
 
 def combine_generator_sums(s):
     """s = [sum D_y2(fake), sum D_dem(attr), sum|attr-real_dem|, sum wr, sum wf, sum wr*wf, n, n*H*W]
-    -> the six scalars of netG_no_update / netG_train (GT:576-598)."""
+    -> the six scalars of netG_no_update / netG_train (GT:576-598).  The library does the same algebra
+    (g_loss_from_sums in csrc/model.hip); this copy serves the tests and external callers of *_grads."""
     n, npix = float(s[6]), float(s[7])
     lf, lfd = float(s[0]) / n, float(s[1]) / n
     m1 = 100.0 * float(s[2]) / npix
@@ -47,47 +60,60 @@ class DataParallel:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.on_device = dist.get_backend(group) == "nccl"
         self._views = {}
+        self.device = None
+        self.calls = 0          # collectives issued (tests / bench report it)
 
-    def _grad_tensor(self, engine, net):
-        if hasattr(engine, "grad_tensor"):          # test doubles / CPU engines
-            return engine.grad_tensor(net)
-        key = (id(engine), net)
-        if key not in self._views:
-            ptr, n = engine.grad_arena(net)
-            self._views[key] = torch.as_tensor(_DevArray(ptr, n), device=engine.device)
-        return self._views[key]
+    # ---- the hook: in-place summing all-reduce of n floats at a raw pointer ----
+    def _view(self, ptr, n):
+        key = (ptr, n)
+        t = self._views.get(key)
+        if t is None:
+            if self.on_device:
+                t = torch.as_tensor(_DevArray(ptr, n), device=self.device)
+            else:                                   # gloo: host memory (CPU tests with an engine double)
+                t = torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n,)))
+            self._views[key] = t
+        return t
 
-    def _allreduce_grads(self, engine, net):
-        # losses are batch means (GT:540-545, 576): the global gradient is the mean of the rank gradients
-        g = self._grad_tensor(engine, net)
-        if dist.get_backend(self.group) == "nccl":
-            dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)    # RCCL averages inside the collective
-        else:                                                            # gloo (CPU tests) has no AVG
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-            g.mul_(1.0 / self.world)
+    def allreduce_ptr(self, ptr, n, stream=0):
+        t = self._view(ptr, n)
+        self.calls += 1
+        if self.on_device:
+            cur = torch.cuda.current_stream(self.device)
+            if stream and cur.cuda_stream != stream:    # the engine was put on another stream: order against THAT one
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                return
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-    def _allreduce_sums(self, engine, n):
-        s = torch.tensor(engine.last_sums()[:n], dtype=torch.float64)
-        dev = getattr(engine, "device", None)
-        if dev is not None and dist.get_backend(self.group) == "nccl":
-            s = s.to(dev)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
-        return s.cpu().tolist()
+    # ---- engine attachment ----
+    def attach(self, engine, nets=("G", "D_y2", "D_dem")):
+        """Makes `engine` one replica of a data-parallel job: rank 0's weights, BN moving statistics and optimiser
+        state replace every other rank's (replicas built from different seeds would otherwise apply the averaged
+        gradient to different models and never agree), then the all-reduce hook is registered."""
+        self.device = getattr(engine, "device", None)
+        for net in nets:
+            for arena in (ARENA_PARAMS, ARENA_NONTRAINABLE, ARENA_ADAM_M, ARENA_ADAM_V):
+                ptr, n = engine.arena(net, arena)
+                if n:
+                    dist.broadcast(self._view(ptr, n), src=self._global_rank0(), group=self.group)
+            t = torch.tensor([engine.adam_step(net)], dtype=torch.int64,
+                             device=self.device if self.on_device else None)
+            dist.broadcast(t, src=self._global_rank0(), group=self.group)
+            engine.adam_step(net, int(t.item()))
+            engine.weights_changed(net)
+        engine.set_allreduce(self.allreduce_ptr, self.world)
+        return engine
 
-    def reduce_critic(self, engine, which, out):
-        self._allreduce_grads(engine, which)
-        return combine_critic_sums(self._allreduce_sums(engine, 4))
+    def _global_rank0(self):
+        return dist.get_global_rank(self.group, 0) if self.group is not None else 0
 
-    def reduce_generator_many(self, sums, device=None):
-        """k x 8 un-normalised pieces -> k x 6 global scalars with ONE all-reduce (same choice on every rank)."""
-        s = torch.tensor(sums, dtype=torch.float64)
-        if device is not None and dist.get_backend(self.group) == "nccl":
-            s = s.to(device)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
-        return [combine_generator_sums(row) for row in s.cpu().tolist()]
-
-    def reduce_generator(self, engine, out, grads):
-        if grads:
-            self._allreduce_grads(engine, "G")
-        return combine_generator_sums(self._allreduce_sums(engine, 8))
+    def shard(self, n_global):
+        """Sample range [lo, hi) of this rank inside a global batch of n_global samples (sharded by sample
+        index, equal shards)."""
+        if n_global % self.world:
+            raise ValueError("global batch %d is not divisible by the world size %d" % (n_global, self.world))
+        per = n_global // self.world
+        return self.rank * per, (self.rank + 1) * per

@@ -26,21 +26,25 @@ def _torch():
 
 class Engine:
     def __init__(self, batch, height=256, width=256, nicg=1, first_fm=32, im_thresh=0.5, delta=10.0, lrD=1e-4,
-                 lrG=1e-4, beta1=0.0, beta2=0.9, adam_eps=1e-7, device=None, nc_out=1, bf16_weights=False):
+                 lrG=1e-4, beta1=0.0, beta2=0.9, adam_eps=1e-7, device=None, nc_out=1, bf16_weights=False,
+                 bf16_mfma=False):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.DepganError("dep_gan_im_amd needs a ROCm GPU (MI355X): torch.cuda.is_available() is False")
         self.lib = load()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         torch.cuda.set_device(self.device)
-        self.cfg = Config(batch, height, width, nicg, first_fm, im_thresh, delta, lrD, lrG, beta1, beta2, adam_eps,
-                          nc_out, 1 if bf16_weights else 0)
+        self.cfg = Config(batch=batch, height=height, width=width, nicg=nicg, first_fm=first_fm, im_thresh=im_thresh,
+                          delta=delta, lrD=lrD, lrG=lrG, beta1=beta1, beta2=beta2, adam_eps=adam_eps, nc_out=nc_out,
+                          bf16_weights=1 if (bf16_weights or bf16_mfma) else 0, bf16_mfma=1 if bf16_mfma else 0)
         self.batch, self.height, self.width, self.nicg, self.nc_out = batch, height, width, nicg, nc_out
         h = C.c_void_p()
         check(self.lib.depgan_create(C.byref(self.cfg), C.byref(h)), "depgan_create")
         self.h = h
         self._use_current_stream()
         self._tables = {}
+        self._ar_cb = None       # keeps the ctypes callback of set_allreduce alive
+        self.world = 1
 
     # ---- plumbing ----
     def _use_current_stream(self):
@@ -146,6 +150,63 @@ class Engine:
         self._use_current_stream()
         check(self.lib.depgan_weights_changed(self.h, nid), "depgan_weights_changed")
 
+    def arena(self, net, arena):
+        """(device pointer, number of floats) of one of a network's flat arenas (weights broadcast, checkpoints)."""
+        nid = NET_IDS[net]
+        return self.lib.depgan_arena_ptr(self.h, nid, arena), self.lib.depgan_arena_floats(self.h, nid, arena)
+
+    def weights_changed(self, net):
+        """Call after writing into a PARAMS / NONTRAINABLE arena from outside: rebuilds the derived state."""
+        self._use_current_stream()
+        check(self.lib.depgan_weights_changed(self.h, NET_IDS[net]), "depgan_weights_changed")
+
+    def set_arena(self, net, arena, values):
+        """Overwrites one flat arena from a float32 array of exactly its length (optimiser state on resume)."""
+        ptr, n = self.arena(net, arena)
+        v = np.ascontiguousarray(values, np.float32).reshape(-1)
+        if v.size != n:
+            raise ValueError("arena of %s has %d floats, got %d" % (net, n, v.size))
+        _torch().cuda.synchronize(self.device)
+        if n:
+            _lib.memcpy(ptr, v.ctypes.data, n * 4, H2D)
+
+    def get_arena(self, net, arena):
+        return self._arena_np(net, arena)[:self.lib.depgan_arena_floats(self.h, NET_IDS[net], arena)].copy()
+
+    def adam_step(self, net, value=None):
+        """Adam `iterations` of a network's optimiser; with `value` sets it (resume)."""
+        if value is not None:
+            check(self.lib.depgan_set_adam_step(self.h, NET_IDS[net], int(value)), "depgan_set_adam_step")
+        return int(self.lib.depgan_get_adam_step(self.h, NET_IDS[net]))
+
+    def set_allreduce(self, fn, world):
+        """Registers the data-parallel hook: fn(dev_ptr:int, n:int, stream:int) must ENQUEUE an in-place summing
+        all-reduce of n device floats on the stream (dist.DataParallel.attach does this).  fn=None removes it."""
+        if fn is None:
+            self._ar_cb, self.world = None, 1
+            check(self.lib.depgan_set_allreduce(self.h, _lib.ALLREDUCE_FN(), None, 1), "depgan_set_allreduce")
+            return
+        self._ar_err = None
+
+        def _cb(user, ptr, n, stream):
+            try:
+                fn(int(ptr), int(n), int(stream or 0))
+                return 0
+            except BaseException as e:   # never let an exception unwind through the C frames
+                self._ar_err = e
+                return 1
+
+        self._ar_cb = _lib.ALLREDUCE_FN(_cb)
+        self.world = int(world)
+        check(self.lib.depgan_set_allreduce(self.h, self._ar_cb, None, int(world)), "depgan_set_allreduce")
+
+    def _check(self, rc, what):
+        err = getattr(self, "_ar_err", None)
+        if err is not None:
+            self._ar_err = None
+            raise err
+        check(rc, what)
+
     def grad_arena(self, net):
         """(device pointer, number of floats) of a network's flat gradient arena (for the RCCL all-reduce)."""
         nid = NET_IDS[net]
@@ -204,7 +265,7 @@ class Engine:
         out = (C.c_float * 2)()
         self._use_current_stream()
         fn = self.lib.depgan_critic_step if update else self.lib.depgan_critic_grads
-        check(fn(self.h, NET_IDS[which], self._p(y2), self._p(x), self._p(z), self._p(ep), out), "critic step")
+        self._check(fn(self.h, NET_IDS[which], self._p(y2), self._p(x), self._p(z), self._p(ep), out), "critic step")
         return [float(out[0]), float(out[1])]
 
     def generator(self, x, y2, z, mode="eval"):
@@ -212,7 +273,7 @@ class Engine:
         out = (C.c_float * 6)()
         self._use_current_stream()
         fn = {"eval": self.lib.depgan_g_eval, "grads": self.lib.depgan_g_grads, "step": self.lib.depgan_g_step}[mode]
-        check(fn(self.h, self._p(x), self._p(y2), self._p(z), out), "generator " + mode)
+        self._check(fn(self.h, self._p(x), self._p(y2), self._p(z), out), "generator " + mode)
         return [float(v) for v in out]
 
     def generator_eval_multi(self, x, y2, zs):
@@ -232,10 +293,69 @@ class Engine:
             raise ValueError("noises must be (k,%d,32,1)" % B)
         out, sums = (C.c_float * (6 * k))(), (C.c_float * (8 * k))()
         self._use_current_stream()
-        check(self.lib.depgan_g_eval_multi(self.h, self._p(x), self._p(y2), self._p(zs), k, out, sums),
-              "depgan_g_eval_multi")
+        self._check(self.lib.depgan_g_eval_multi(self.h, self._p(x), self._p(y2), self._p(zs), k, out, sums),
+                    "depgan_g_eval_multi")
         return ([[float(out[6 * i + j]) for j in range(6)] for i in range(k)],
                 [[float(sums[8 * i + j]) for j in range(8)] for i in range(k)])
+
+    def gen_iteration(self, y2_loop, dem_loop, gen, batch_stride=None):
+        """One generator iteration of the reference schedule (GT:791-878) with ONE host synchronisation
+        (depgan_gen_iteration).
+
+        y2_loop / dem_loop: (x, y2, z, ep, n) -- n consecutive batches: x (n*stride.., H, W, nicg) and y2 device
+        tensors whose batch j starts at sample j*batch_stride, z (n, B, 32[,1]), ep (n, B[,1,1,1]); n may be 0.
+        gen: (x, y2, zs) -- one batch and its k noises (k, B, 32[,1]).
+        Returns (critic_y2 outs n x 2, critic_dem outs n x 2, eval outs k x 6, train out 6, best index)."""
+        torch = _torch()
+        B = self.batch
+        stride = B if batch_stride is None else int(batch_stride)
+
+        def loop(t):
+            x, y2, z, ep, n = t
+            n = int(n)
+            if n == 0:
+                return None, None, None, None, 0
+            x, y2 = self._dev(x), self._dev(y2)
+            need = (n - 1) * stride + B
+            if x.shape[0] < need or y2.shape[0] < need or tuple(x.shape[1:]) != (self.height, self.width, self.nicg) \
+                    or tuple(y2.shape[1:]) != (self.height, self.width, 1):
+                raise ValueError("critic loop: need %d samples of (%d,%d,%d) / (%d,%d,1), got %s / %s"
+                                 % (need, self.height, self.width, self.nicg, self.height, self.width,
+                                    tuple(x.shape), tuple(y2.shape)))
+            z, ep = self._dev(z).reshape(-1), self._dev(ep).reshape(-1)
+            if z.numel() != n * B * 32 or ep.numel() != n * B:
+                raise ValueError("critic loop: noise must be (%d,%d,32,1) and ep (%d,%d,1,1,1)" % (n, B, n, B))
+            return x, y2, z, ep, n
+
+        xa, ya, za, ea, na = loop(y2_loop)
+        xb, yb, zb, eb, nb = loop(dem_loop)
+        xg, yg, zs = gen
+        xg = self._dev(xg, (B, self.height, self.width, self.nicg))
+        yg = self._dev(yg, (B, self.height, self.width, 1))
+        zs = self._dev(zs)
+        k = int(zs.shape[0])
+        zs = zs.reshape(k, -1).contiguous()
+        if zs.shape[1] != B * 32:
+            raise ValueError("noises must be (k,%d,32,1)" % B)
+        if na + nb > _lib.MAX_CRITIC_STEPS or not 1 <= k <= _lib.MAX_MULTI:
+            raise ValueError("gen_iteration: at most %d critic updates and %d noises" % (_lib.MAX_CRITIC_STEPS,
+                                                                                       _lib.MAX_MULTI))
+        nout = 2 * (na + nb) + 6 * k + 6
+        out, best = (C.c_float * nout)(), C.c_int(-1)
+        p = lambda t: self._p(t) if t is not None else C.c_void_p(0)   # noqa: E731
+        self._use_current_stream()
+        self._check(self.lib.depgan_gen_iteration(self.h, p(xa), p(ya), p(za), p(ea), na, p(xb), p(yb), p(zb), p(eb),
+                                                  nb, stride, self._p(xg), self._p(yg), self._p(zs), k, out,
+                                                  C.byref(best)), "depgan_gen_iteration")
+        v = [float(t) for t in out]
+        o = 0
+        cy = [v[o + 2 * j:o + 2 * j + 2] for j in range(na)]
+        o += 2 * na
+        cd = [v[o + 2 * j:o + 2 * j + 2] for j in range(nb)]
+        o += 2 * nb
+        ev = [v[o + 6 * i:o + 6 * i + 6] for i in range(k)]
+        o += 6 * k
+        return cy, cd, ev, v[o:o + 6], int(best.value)
 
     # ---- DEP-UResNet supervised path (nc_out = 4) ----
     def uresnet(self, x, z, labels, mode="step", drop_seed=0):

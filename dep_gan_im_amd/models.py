@@ -35,8 +35,16 @@ def _glorot_uniform(rng, shape, fan_in, fan_out):
     return rng.uniform(-lim, lim, size=shape).astype(np.float32)
 
 
+# keras.initializers.he_normal = VarianceScaling(scale=2, mode='fan_in', distribution='normal'): a normal truncated at
+# two standard deviations.  From Keras 2.2.3 on the sampled stddev is divided by .87962566103423978 (the standard deviation
+# of the truncated unit normal) so that the RESULT has std sqrt(2/fan_in); earlier 2.x releases omit the correction
+# (version-sensitive, unverifiable here).  The reference needs Python 2 + TF 1.x, for which 2.2.4 was the
+# common release, so the corrected form is used -- the same constant as oracle/depgan_oracle.py::_he_normal.
+HE_NORMAL_TRUNC_STD = 0.87962566103423978
+
+
 def _he_normal(rng, shape, fan_in):
-    std = math.sqrt(2.0 / fan_in)
+    std = math.sqrt(2.0 / fan_in) / HE_NORMAL_TRUNC_STD
     v = rng.standard_normal(size=shape)
     bad = np.abs(v) > 2
     while bad.any():

@@ -20,7 +20,15 @@ extern "C" {
 
 typedef struct depgan_ctx depgan_ctx;
 
+/* ABI guard: bump when depgan_config or the meaning of an entry point changes.  depgan_create rejects a
+ * depgan_config whose struct_size is not sizeof(depgan_config) of THIS header (a caller compiled or bound against an
+ * older layout would otherwise make the library read past its struct). */
+#define DEPGAN_ABI_VERSION 2
+int depgan_abi_version(void);
+size_t depgan_config_size(void);
+
 typedef struct depgan_config {
+  int struct_size;  /* = sizeof(depgan_config); checked by depgan_create                */
   int batch;        /* per-device batch size (batchSize, GT:42)                       */
   int height;       /* imageSize (GT:40); must be a multiple of 16                    */
   int width;
@@ -34,6 +42,9 @@ typedef struct depgan_config {
                        0 is read as 1.                                                    */
   int bf16_weights; /* BASELINE config 4: 1 = every "/kernel" tensor is rounded to bf16 (RNE) before use, products
                        accumulate in fp32, the fp32 master copy and the Adam state stay fp32; 0 = fp32 weights */
+  int bf16_mfma;    /* BASELINE config 4 on the bf16 matrix pipe (needs bf16_weights = 1): the MFMA convolutions round
+                       their activation operand to bf16 (RNE) while staging it and run v_mfma_f32_32x32x16_bf16 with
+                       fp32 accumulation; everything between the convolutions stays fp32.  0 = fp32 matrix pipe  */
 } depgan_config;
 
 enum { DEPGAN_NET_G = 0, DEPGAN_NET_D_Y2 = 1, DEPGAN_NET_D_DEM = 2 };
@@ -48,6 +59,17 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out);
 void depgan_destroy(depgan_ctx* ctx);
 /* all work is enqueued on this hipStream_t (default: the null stream) */
 int depgan_set_stream(depgan_ctx* ctx, void* hip_stream);
+
+/* Data parallelism (the reference is single-GPU, GT:13).  The library stays free of any communication
+ * dependency: the host registers ONE function that all-reduces (sum) n device floats in place across the ranks,
+ * ENQUEUED on hip_stream (RCCL via torch.distributed in dep_gan_im_amd/dist.py); it must not synchronise the host.
+ * With a hook registered every *_step / depgan_gen_iteration / depgan_g_eval_multi call all-reduces, per network
+ * update, that network's gradient arena together with the un-normalised loss pieces (one message), divides the
+ * gradient by `world` inside Adam and reports GLOBAL scalars, identical on every rank (hence the same best-of-k
+ * noise choice).  *_grads calls never communicate.  fn == NULL removes the hook; world = 1 with a hook is a one-rank
+ * job (the hook is still called). */
+typedef int (*depgan_allreduce_fn)(void* user, float* dev_ptr, long n, void* hip_stream);
+int depgan_set_allreduce(depgan_ctx* ctx, depgan_allreduce_fn fn, void* user, int world);
 
 /* model.trainable_weights / get_weights / set_weights (GT:549, 892; GE:383) */
 int depgan_param_count(depgan_ctx* ctx, int net);
@@ -82,6 +104,27 @@ int depgan_g_eval_multi(depgan_ctx* ctx, const float* x_dev, const float* y2_dev
                         float* out_host, float* sums_host);
 int depgan_g_step(depgan_ctx* ctx, const float* x_dev, const float* y2_dev, const float* z_dev, float out_host[6]);
 int depgan_apply_adam(depgan_ctx* ctx, int net);
+/* Adam `iterations` of a network's optimiser (GT:549, 568, 594), for checkpoint / resume */
+long depgan_get_adam_step(depgan_ctx* ctx, int net);
+int depgan_set_adam_step(depgan_ctx* ctx, int net, long t);
+
+/* One generator iteration of the reference schedule (GT:791-829, 868-878) with ONE host synchronisation:
+ *   n_y2  critic-Y2 updates  on the batches  x_y2 + j*stride, y2_y2 + j*stride_y   (j = 0 .. n_y2-1)   GT:802-814
+ *   n_dem critic-DEM updates on the batches  x_dem + j*stride, ...                                        GT:817-829
+ *   k evaluations of the generator loss on (x_gen, y2_gen) with the noises z_gen[0..k)                    GT:868-874
+ *   arg-min of the total loss (first minimum of the float32 values, as np.argmin)                         GT:875-876
+ *   one generator update with that noise                                                                  GT:878
+ * everything enqueued back to back (the arg-min and the noise gather run on the device), all scalars fetched at the
+ * end.  batch_stride = samples between the starts of consecutive batches (batch for data resident in HBM as one
+ * array; world*batch when the rank takes every world-th batch).  z_*: (n, batch, 32), ep_*: (n, batch).
+ * out_host: n_y2 x 2 [loss_real, loss_fake], then n_dem x 2, then k x 6, then the 6 scalars of the update
+ * (2 n_y2 + 2 n_dem + 6 k + 6 floats); *best_host = chosen noise index.  n_y2, n_dem >= 0, 1 <= k <= DEPGAN_MAX_MULTI;
+ * n_y2 + n_dem <= DEPGAN_MAX_CRITIC_STEPS. */
+#define DEPGAN_MAX_CRITIC_STEPS 256
+int depgan_gen_iteration(depgan_ctx* ctx, const float* x_y2, const float* y2_y2, const float* z_y2, const float* ep_y2,
+                         int n_y2, const float* x_dem, const float* y2_dem, const float* z_dem, const float* ep_dem,
+                         int n_dem, long batch_stride, const float* x_gen, const float* y2_gen, const float* z_gen, int k,
+                         float* out_host, int* best_host);
 
 /* DEP-UResNet supervised path (DEP-UResNet-wNoises-training-4fold.py "UT"; contexts created with nc_out = 4):
  * my_network.fit / train_on_batch (UT:427, 602-606) = learning phase 1: batch-statistics BatchNorm with

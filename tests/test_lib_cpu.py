@@ -61,7 +61,12 @@ def test_keras_default_initialisers():
     lim = np.sqrt(6.0 / (9 * 32 + 9 * 32))
     assert k.shape == (3, 3, 32, 32) and np.abs(k).max() <= lim and np.abs(k).max() > 0.9 * lim
     hk = w["dense_noise_2_mul/kernel"]
-    assert hk.shape == (1024, 128) and abs(hk.std() / np.sqrt(2.0 / 1024) - 0.88) < 0.05   # truncated normal
+    # truncated normal whose RESULT has std sqrt(2/fan_in) (Keras >= 2.2.3; models.HE_NORMAL_TRUNC_STD), never beyond
+    # two sampled standard deviations -- and the same definition as the oracle's initialiser
+    assert hk.shape == (1024, 128) and abs(hk.std() / np.sqrt(2.0 / 1024) - 1.0) < 0.03
+    assert np.abs(hk).max() <= 2.0 * np.sqrt(2.0 / 1024) / models.HE_NORMAL_TRUNC_STD + 1e-7
+    ok = O.init_generator(5)["dense_noise_2_mul/kernel"]
+    assert abs(ok.std() / hk.std() - 1.0) < 0.03
 
 
 def test_host_save_load_and_errors(tmp_path):
@@ -83,3 +88,52 @@ def test_host_save_load_and_errors(tmp_path):
     lines = []
     d.summary(print_fn=lines.append)
     assert any("1798002" in ln for ln in lines)
+
+
+def _header_config_fields():
+    hdr = open(os.path.join(ROOT, "include", "depgan.h")).read()
+    body = re.search(r"typedef struct depgan_config \{(.*?)\} depgan_config;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.split(None, 1)
+        fields += [(n.strip(), ctype) for n in names.split(",")]
+    return fields
+
+
+def test_config_struct_matches_header_binding_and_integration_doc(lib):
+    import ctypes as C
+    fields = _header_config_fields()
+    assert fields[0] == ("struct_size", "int")
+    ctypes_of = {"int": C.c_int, "float": C.c_float}
+    assert [(n, ctypes_of[t]) for n, t in fields] == list(_lib.Config._fields_)
+    assert lib.depgan_config_size() == C.sizeof(_lib.Config) == 4 * len(fields)
+    hdr = open(os.path.join(ROOT, "include", "depgan.h")).read()
+    assert int(re.search(r"#define DEPGAN_ABI_VERSION (\d+)", hdr).group(1)) == lib.depgan_abi_version() \
+        == _lib.ABI_VERSION
+    # the stub a maintainer would copy out of INTEGRATION.md declares the same struct
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class Config(C.Structure)"):]
+    stub = stub[:stub.index("ctx = C.c_void_p()")]
+    doc_fields = re.findall(r'\("([a-z0-9_A-Z]+)", C\.c_(int|float)\)', stub)
+    assert doc_fields == fields
+    assert "depgan_abi_version() == %d" % _lib.ABI_VERSION in stub
+    kw = re.search(r"cfg = Config\((.*?)\)\n", stub, re.S).group(1)
+    assert [k.strip().split("=")[0] for k in kw.split(",")] == [n for n, _ in fields]
+
+
+def test_create_rejects_a_config_of_another_size(lib):
+    """No GPU needed: the size check comes before any HIP call."""
+    import ctypes as C
+    cfg = _lib.Config(batch=2, height=64, width=64, nicg=1, first_fm=32, im_thresh=0.5, delta=10.0, lrD=1e-4, lrG=1e-4,
+                      beta1=0.0, beta2=0.9, adam_eps=1e-7, nc_out=1)
+    assert cfg.struct_size == C.sizeof(_lib.Config)
+    cfg.struct_size -= 4                     # what a caller bound to the previous header would pass
+    h = C.c_void_p()
+    assert lib.depgan_create(C.byref(cfg), C.byref(h)) != 0 and not h.value
+    assert b"struct_size" in lib.depgan_last_error()
+    cfg.struct_size = 0                      # a caller that never heard of the field
+    assert lib.depgan_create(C.byref(cfg), C.byref(h)) != 0
