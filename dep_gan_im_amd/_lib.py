@@ -19,7 +19,7 @@ EXPORTS = [
     "depgan_op_maxpool", "depgan_op_conv2d_stamps", "depgan_uresnet_grads", "depgan_uresnet_step",
     "depgan_uresnet_eval", "depgan_profile_read_bytes", "depgan_g_eval_multi", "depgan_eval_accumulate", "depgan_eval_counts",
     "depgan_data_prep_scratch_floats", "depgan_data_prep_subject", "depgan_abi_version", "depgan_config_size",
-    "depgan_set_allreduce", "depgan_get_adam_step", "depgan_set_adam_step", "depgan_gen_iteration",
+    "depgan_set_allreduce", "depgan_get_adam_step", "depgan_set_adam_step", "depgan_gen_iteration", "depgan_eval_divide",
 ]
 
 ABI_VERSION = 2          # DEPGAN_ABI_VERSION of the include/depgan.h this binding was written against
@@ -110,8 +110,9 @@ def load():
     lib.depgan_op_conv2d.argtypes = [vp, vp, vp, vp] + [C.c_int] * 8 + [vp]
     lib.depgan_op_conv2d_bwd_data.argtypes = [vp, vp, vp] + [C.c_int] * 7 + [vp]
     lib.depgan_op_conv2d_wgrad.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp]
-    lib.depgan_eval_accumulate.argtypes = [vp, vp, vp, C.c_long, C.c_float, vp]
-    lib.depgan_eval_counts.argtypes = [vp, C.c_int] + [vp] * 7 + [C.c_long, C.c_float, C.POINTER(C.c_longlong), vp]
+    lib.depgan_eval_accumulate.argtypes = [vp, vp, vp, C.c_long, vp]
+    lib.depgan_eval_divide.argtypes = [vp, C.c_long, C.c_double, vp]
+    lib.depgan_eval_counts.argtypes = [vp, C.c_int] + [vp] * 7 + [C.c_long, C.c_double, C.POINTER(C.c_longlong), vp]
     lib.depgan_data_prep_scratch_floats.argtypes = [C.c_int] * 3
     lib.depgan_data_prep_scratch_floats.restype = C.c_size_t
     lib.depgan_data_prep_subject.argtypes = [vp] * 7 + [C.c_int] * 4 + [vp] * 4

@@ -1523,13 +1523,17 @@ int depgan_op_maxpool(const float* in, float* out, int B, int Ho, int Wo, int C,
 }
 
 // ---- evaluation step after the path (GE:616-807): stateless, caller's stream ----
-int depgan_eval_accumulate(const float* pred, const float* mask, float* acc, long n, float weight, void* stream) {
+int depgan_eval_accumulate(const float* pred, const float* mask, double* acc, long n, void* stream) {
   if (!pred || !acc || n < 0) { dg_set_error("eval_accumulate: null argument"); return DG_ERR_ARG; }
-  return dg_eval_accumulate(pred, mask, acc, (size_t)n, weight, (hipStream_t)stream);
+  return dg_eval_accumulate(pred, mask, acc, (size_t)n, (hipStream_t)stream);
 }
-int depgan_eval_counts(const float* x, int nicg, const float* pred, const float* code_real, const float* mask1,
+int depgan_eval_divide(double* acc, long n, double divisor, void* stream) {
+  if (!acc || n < 0) { dg_set_error("eval_divide: null argument"); return DG_ERR_ARG; }
+  return dg_eval_divide(acc, (size_t)n, divisor, (hipStream_t)stream);
+}
+int depgan_eval_counts(const float* x, int nicg, const double* pred, const float* code_real, const float* mask1,
                        const float* wmh1, const float* mask2, const float* wmh2, const float* prob2, long npix,
-                       float thr, long long out_host[DEPGAN_EVAL_NCOUNT], void* stream) {
+                       double thr, long long out_host[DEPGAN_EVAL_NCOUNT], void* stream) {
   if (!x || !pred || !out_host || nicg < 1 || npix < 0) { dg_set_error("eval_counts: bad argument"); return DG_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* dev = nullptr;

@@ -108,7 +108,8 @@ int dg_best_noise(const float* stats, int k, const float* z_all, long zfloats, i
 int dg_round_bf16_masked(const float* src, const unsigned char* mask, float* dst, size_t n, hipStream_t st);
 
 // evaluation step after the path (GE:616-807)
-int dg_eval_accumulate(const float* pred, const float* mask, float* acc, size_t n, float weight, hipStream_t st);
-int dg_eval_counts(const float* x, int nicg, const float* pred, const float* code_real, const float* mask1,
-                   const float* wmh1, const float* mask2, const float* wmh2, const float* prob2, size_t npix, float thr,
+int dg_eval_accumulate(const float* pred, const float* mask, double* acc, size_t n, hipStream_t st);
+int dg_eval_divide(double* acc, size_t n, double d, hipStream_t st);
+int dg_eval_counts(const float* x, int nicg, const double* pred, const float* code_real, const float* mask1,
+                   const float* wmh1, const float* mask2, const float* wmh2, const float* prob2, size_t npix, double thr,
                    unsigned long long* out_dev, hipStream_t st);

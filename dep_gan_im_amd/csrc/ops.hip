@@ -944,15 +944,26 @@ int dg_round_bf16_masked(const float* src, const unsigned char* mask, float* dst
 // evaluation step after the path (DEP-GAN_testing_4fold.py "GE":616-807)
 // ---------------------------------------------------------------------------
 // acc += weight * pred * mask   (GE:623-625: the running sum of the n_repeat masked predictions)
+// GE:617-624: the running sum is float64 (np.zeros), each term the float32 product prediction * mask
 __global__ void eval_accumulate_kernel(const float* __restrict__ pred, const float* __restrict__ mask,
-                                       float* __restrict__ acc, size_t n, float weight) {
+                                       double* __restrict__ acc, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float m = mask ? mask[i] : 1.0f;
-    acc[i] = __fadd_rn(acc[i], __fmul_rn(__fmul_rn(pred[i], m), weight));
+    acc[i] = __dadd_rn(acc[i], (double)__fmul_rn(pred[i], m));
   }
 }
-int dg_eval_accumulate(const float* pred, const float* mask, float* acc, size_t n, float weight, hipStream_t st) {
-  hipLaunchKernelGGL(eval_accumulate_kernel, dim3(nblk(n, 2048)), dim3(256), 0, st, pred, mask, acc, n, weight);
+int dg_eval_accumulate(const float* pred, const float* mask, double* acc, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(eval_accumulate_kernel, dim3(nblk(n, 2048)), dim3(256), 0, st, pred, mask, acc, n);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+// GE:628: output_img_pred_mean / float(n_repeat), a float64 division
+__global__ void eval_divide_kernel(double* __restrict__ acc, size_t n, double d) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc[i] = __ddiv_rn(acc[i], d);
+}
+int dg_eval_divide(double* acc, size_t n, double d, hipStream_t st) {
+  hipLaunchKernelGGL(eval_divide_kernel, dim3(nblk(n, 2048)), dim3(256), 0, st, acc, n, d);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
@@ -964,11 +975,15 @@ int dg_eval_accumulate(const float* pred, const float* mask, float* acc, size_t 
 //  [5+3(k-1) ..] for k = 1,2,3: #(fake_code == k & real_code == k), #(real_code == k), #(fake_code == k)
 //  [14..16] the same for code > 0 (whole WMH), [17..19] for code in {1,2} (changing WMH)
 #define DG_EVAL_NCOUNT 20
-__global__ void eval_counts_kernel(const float* __restrict__ x, int nicg, const float* __restrict__ pred,
+// dtypes follow the reference's NumPy statements: the mean prediction is float64, so fake = x0 + pred, its clip and
+// its comparisons run in float64 against the float64 threshold; x and prob2 are float32 arrays, which NumPy compares
+// with a Python-float threshold in float32.
+__global__ void eval_counts_kernel(const float* __restrict__ x, int nicg, const double* __restrict__ pred,
                                    const float* __restrict__ code_real, const float* __restrict__ mask1,
                                    const float* __restrict__ wmh1, const float* __restrict__ mask2,
                                    const float* __restrict__ wmh2, const float* __restrict__ prob2, size_t npix,
-                                   float thr, unsigned long long* __restrict__ out) {
+                                   double thr_d, unsigned long long* __restrict__ out) {
+  const float thr = (float)thr_d;
   __shared__ unsigned int sh[DG_EVAL_NCOUNT];
   if (threadIdx.x < DG_EVAL_NCOUNT) sh[threadIdx.x] = 0;
   __syncthreads();
@@ -977,15 +992,15 @@ __global__ void eval_counts_kernel(const float* __restrict__ x, int nicg, const 
   for (int k = 0; k < DG_EVAL_NCOUNT; ++k) c[k] = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
     const float x0 = x[i * nicg];
-    float fake = __fadd_rn(x0, pred[i]);
-    fake = fake < -1.0f ? -1.0f : (fake > 1.0f ? 1.0f : fake);
+    double fake = __dadd_rn((double)x0, pred[i]);
+    fake = fake < -1.0 ? -1.0 : (fake > 1.0 ? 1.0 : fake);
     if (mask1 && wmh1) c[0] += (__fmul_rn(mask1[i], wmh1[i]) != 0.0f);
     if (mask2 && wmh2) c[1] += (__fmul_rn(mask2[i], wmh2[i]) != 0.0f);
     for (int ch = 0; ch < nicg; ++ch) c[2] += (x[i * nicg + ch] >= thr);
     if (prob2) c[3] += (prob2[i] >= thr);
     const float m2 = mask2 ? mask2[i] : 1.0f;
-    c[4] += (fake > thr) && (m2 != 0.0f);
-    const bool fhi = fake >= thr, xhi = x0 >= thr;
+    c[4] += (fake > thr_d) && (m2 != 0.0f);
+    const bool fhi = fake >= thr_d, xhi = x0 >= thr;
     const int fc = (!fhi && xhi) ? 1 : ((fhi && !xhi) ? 2 : ((fhi && xhi) ? 3 : 0));
     const float rcf = code_real ? code_real[i] : 0.0f;
 #pragma unroll
@@ -1010,8 +1025,8 @@ __global__ void eval_counts_kernel(const float* __restrict__ x, int nicg, const 
   __syncthreads();
   if (threadIdx.x < DG_EVAL_NCOUNT && sh[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
 }
-int dg_eval_counts(const float* x, int nicg, const float* pred, const float* code_real, const float* mask1,
-                   const float* wmh1, const float* mask2, const float* wmh2, const float* prob2, size_t npix, float thr,
+int dg_eval_counts(const float* x, int nicg, const double* pred, const float* code_real, const float* mask1,
+                   const float* wmh1, const float* mask2, const float* wmh2, const float* prob2, size_t npix, double thr,
                    unsigned long long* out_dev, hipStream_t st) {
   HIPCHECK(hipMemsetAsync(out_dev, 0, DG_EVAL_NCOUNT * sizeof(unsigned long long), st));
   hipLaunchKernelGGL(eval_counts_kernel, dim3(nblk(npix, 1024)), dim3(256), 0, st, x, nicg, pred, code_real, mask1, wmh1,

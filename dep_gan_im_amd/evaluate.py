@@ -5,9 +5,10 @@
                     icv_and_sl_mask_2tp, brain_wmh_2tp, brain_prob__2tp, voxel_volume, TRSH_VAL) # GE:637-790
     m["vol_dsc"]   # the 18-entry row the script appends per subject (GE:806-808)
 
-The mean over the n_repeat noise draws is accumulated on the device, and the volumes / Dice figures come from one
-integer census kernel (exact counts); only the two dozen integers travel to the host, where the reference's own
-scalar algebra is applied.
+The mean over the n_repeat noise draws is accumulated on the device in float64 like the reference's np.zeros
+accumulator (GE:617), and the volumes / Dice figures come from one integer census kernel (exact counts) that thresholds
+that float64 mean in float64; only the two dozen integers travel to the host, where the reference's own scalar
+algebra is applied.
 """
 from __future__ import annotations
 
@@ -25,13 +26,15 @@ def _torch():
     return torch
 
 
-def _dev(a, device):
+def _dev(a, device, dtype=None):
     torch = _torch()
     if a is None:
         return None
+    dtype = dtype or torch.float32
     if isinstance(a, torch.Tensor):
-        return a.to(device=device, dtype=torch.float32).contiguous()
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.float32)).to(device)
+        return a.to(device=device, dtype=dtype).contiguous()
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=npdt)).to(device)
 
 
 def _p(t):
@@ -40,7 +43,8 @@ def _p(t):
 
 def predict_mean(netG, x, n_repeat=10, mask=None, noise_size=32, rng=None, batch_size=32):
     """Mean of n_repeat generator predictions with fresh N(0,1) noise, each multiplied by `mask` (GE:616-628).
-    x: (n, H, W, nicg); mask: (n, H, W) or None.  Returns a CUDA tensor (n, H, W)."""
+    x: (n, H, W, nicg); mask: (n, H, W) or None.  Returns a float64 CUDA tensor (n, H, W): the reference's running
+    sum is float64 and so is the mean it thresholds (GE:617, 628)."""
     torch = _torch()
     lib = _lib.load()
     rng = rng if rng is not None else np.random
@@ -51,17 +55,15 @@ def predict_mean(netG, x, n_repeat=10, mask=None, noise_size=32, rng=None, batch
     md = _dev(mask, dev)
     if md is not None and md.numel() != n * eng.height * eng.width:
         raise ValueError("mask must have one value per output pixel")
-    acc = torch.zeros((n, eng.height, eng.width), dtype=torch.float32, device=dev)
+    acc = torch.zeros((n, eng.height, eng.width), dtype=torch.float64, device=dev)                  # GE:617
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for _ in range(n_repeat):
         noise = rng.normal(size=(n, noise_size, 1)).astype("float32")               # GE:620
         pred = eng.g_forward(xd, noise)                                               # GE:621
-        _lib.check(lib.depgan_eval_accumulate(_p(pred), _p(md), _p(acc), acc.numel(), 1.0, stream),
-                   "depgan_eval_accumulate")
-    out = torch.zeros_like(acc)
-    _lib.check(lib.depgan_eval_accumulate(_p(acc), None, _p(out), acc.numel(), 1.0 / float(n_repeat), stream),
-               "depgan_eval_accumulate")                                              # GE:628
-    return out
+        _lib.check(lib.depgan_eval_accumulate(_p(pred), _p(md), _p(acc), acc.numel(), stream),
+                   "depgan_eval_accumulate")                                          # GE:623-624
+    _lib.check(lib.depgan_eval_divide(_p(acc), acc.numel(), float(n_repeat), stream), "depgan_eval_divide")  # GE:628
+    return acc
 
 
 def census(x, pred, code_real=None, mask1=None, wmh1=None, mask2=None, wmh2=None, prob2=None, thr=0.5, device=None):
@@ -75,7 +77,7 @@ def census(x, pred, code_real=None, mask1=None, wmh1=None, mask2=None, wmh2=None
         raise ValueError("x must be (..., nicg)")
     nicg = int(xd.shape[-1])
     npix = xd.numel() // nicg
-    arrs = [_dev(a, device) for a in (pred, code_real, mask1, wmh1, mask2, wmh2, prob2)]
+    arrs = [_dev(pred, device, torch.float64)] + [_dev(a, device) for a in (code_real, mask1, wmh1, mask2, wmh2, prob2)]
     for name, a in zip(("pred", "code_real", "mask1", "wmh1", "mask2", "wmh2", "prob2"), arrs):
         if a is not None and a.numel() != npix:
             raise ValueError("%s must have %d elements, got %d" % (name, npix, a.numel()))

@@ -157,21 +157,24 @@ int depgan_profile_reset(depgan_ctx* ctx);
 int depgan_profile_dump(depgan_ctx* ctx, const char* path);
 
 /* ---- evaluation step after the path (DEP-GAN_testing_4fold.py "GE":616-807) ----
- * Stateless; device pointers; work is enqueued on `stream`.
- * depgan_eval_accumulate: acc += weight * pred * mask (mask may be NULL) -- the running sum of the n_repeat
- *   masked predictions (GE:618-628).
+ * Stateless; device pointers; work is enqueued on `stream`.  Number types follow the reference's NumPy statements:
+ * depgan_eval_accumulate: acc += (double)(pred * mask) (mask may be NULL) -- the float64 running sum (np.zeros,
+ *   GE:617) of the n_repeat float32 masked predictions (GE:618-624);  depgan_eval_divide: acc /= divisor in float64
+ *   (GE:628: output_img_pred_mean / float(n_repeat)).
  * depgan_eval_counts: the integer census behind the volumes and the six Dice figures (GE:637-790):
- *   x (npix, nicg) input maps, pred (npix) mean predicted DEM; optional (NULL = absent) code_real (npix, values
- *   0..3), mask1 / wmh1 / mask2 / wmh2 / prob2 (npix).  out_host:
- *   [0] nnz(mask1*wmh1) [1] nnz(mask2*wmh2) [2] #(x >= thr) [3] #(prob2 >= thr) [4] nnz(mask2*[fake > thr]) with
- *   fake = clip(x0 + pred, -1, 1); change code of the prediction 1 shrink / 2 grow / 3 stay; then triples
+ *   x (npix, nicg) float32 input maps, pred (npix) FLOAT64 mean predicted DEM; optional (NULL = absent) code_real
+ *   (npix, values 0..3), mask1 / wmh1 / mask2 / wmh2 / prob2 (npix).  fake = clip(x0 + pred, -1, 1) and its
+ *   comparisons run in float64 against thr; the float32 arrays x and prob2 are compared against (float)thr, as NumPy
+ *   does for a float32 array and a Python float.  out_host:
+ *   [0] nnz(mask1*wmh1) [1] nnz(mask2*wmh2) [2] #(x >= thr) [3] #(prob2 >= thr) [4] nnz(mask2*[fake > thr]);
+ *   change code of the prediction 1 shrink / 2 grow / 3 stay; then triples
  *   (#both, #real, #fake) for code 1, 2, 3 at [5..13], for code > 0 at [14..16], for code in {1,2} at [17..19]. */
 #define DEPGAN_EVAL_NCOUNT 20
-int depgan_eval_accumulate(const float* pred_dev, const float* mask_dev, float* acc_dev, long n, float weight,
-                           void* stream);
-int depgan_eval_counts(const float* x_dev, int nicg, const float* pred_dev, const float* code_real_dev,
+int depgan_eval_accumulate(const float* pred_dev, const float* mask_dev, double* acc_dev, long n, void* stream);
+int depgan_eval_divide(double* acc_dev, long n, double divisor, void* stream);
+int depgan_eval_counts(const float* x_dev, int nicg, const double* pred_dev, const float* code_real_dev,
                        const float* mask1_dev, const float* wmh1_dev, const float* mask2_dev, const float* wmh2_dev,
-                       const float* prob2_dev, long npix, float thr, long long out_host[DEPGAN_EVAL_NCOUNT],
+                       const float* prob2_dev, long npix, double thr, long long out_host[DEPGAN_EVAL_NCOUNT],
                        void* stream);
 
 /* ---- data step in front of the path (DEP-GAN_PROB_IM_twoCritics_training_4fold.py "GT": 93-118 load_data /

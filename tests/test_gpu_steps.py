@@ -1,0 +1,368 @@
+"""GPU parity of multi-step behaviour through the C ABI: Adam beyond t = 1, three-step trajectories of each network
+against the fp64 oracle, the one-synchronisation generator iteration against the closure-by-closure schedule, and
+training-state checkpoints (resume is bit-identical).
+
+Why the trajectory tolerances look the way they do.  Keras Adam with beta_1 = 0 (GT:549) moves every weight by
+lr_t * g / (sqrt(v) + eps): the first step is +-lr whatever |g| is, so an element whose gradient is zero to within
+rounding flips sign for free (2 lr apart) -- on both sides of any comparison, the CPU oracle's fp32 and fp64 runs
+included.  Weights are therefore compared (a) exactly, on gradients injected into the arena (the Adam kernel itself:
+v accumulation, lr_t(t), eps placement), and (b) along real trajectories through quantities that are smooth in the
+gradient -- the second-moment arena v after three steps, the last gradient m, the loss scalars of steps 2 and 3 (they
+see the updated weights) -- plus the weights themselves on the elements whose gradient is not rounding-sized."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def srel(got, want):
+    return max(abs(a - b) / (abs(b) + 1e-3) for a, b in zip(got, want))
+
+
+def _setup(img, B, seed, nb=1):
+    """Tie-free (noisy) inputs: nb batches of B samples."""
+    from oracle import depgan_oracle as O
+    PG = O.init_generator(seed, bias_std=0.05)
+    PD1 = O.init_critic(seed + 1, bias_std=0.05, img=img)
+    PD2 = O.init_critic(seed + 2, bias_std=0.05, img=img)
+    x, y2, z, ep = O.synth_batch(seed + 5, B * nb, img, img)
+    rng = np.random.default_rng(seed)
+    x = (x + 0.02 * rng.uniform(size=x.shape)).astype(np.float32)
+    y2 = (y2 + 0.02 * rng.uniform(size=y2.shape)).astype(np.float32)
+    return PG, PD1, PD2, x, y2, z, ep
+
+
+def _trainers(img, B, PG, PD1, PD2, **kw):
+    import dep_gan_im_amd as dg
+    nets = [dg.Gen_UNet2D((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1))]
+    for n, P in zip(nets, (PG, PD1, PD2)):
+        n.set_weights({k: v.copy() for k, v in P.items()})
+    return dg.build_trainers(*nets, batchSize=B, **kw), nets
+
+
+def test_adam_kernel_three_steps_on_injected_gradients(lib):
+    """Keras Adam (App. B.6) over the flat arena: gradients written into the GRADS arena, depgan_apply_adam, three
+    times, against oracle.KerasAdam on the same numbers.  Exercises v accumulation, lr_t(t) = lr sqrt(1-b2^t)/(1-b1^t)
+    and the eps placement, for the GAN optimiser (0, 0.9) and for the supervised one (0.9, 0.999)."""
+    from dep_gan_im_amd import Engine, _lib
+    from oracle import depgan_oracle as O
+    for b1, b2, nc_out, net in ((0.0, 0.9, 1, "D_y2"), (0.9, 0.999, 4, "G")):
+        eng = Engine(2, 64, 64, 1, beta1=b1, beta2=b2, nc_out=nc_out)
+        P = (O.init_critic(5, img=64) if net == "D_y2" else O.init_generator(5, nc_out=4))
+        eng.set_weights(net, P)
+        names = O.trainable_names(P)
+        opt = O.KerasAdam(names, 1e-4, b1, b2)
+        table = {n: (off, int(np.prod(s))) for n, s, off, tr in eng.param_table(net) if tr}
+        n_arena = eng.arena(net, _lib.ARENA_GRADS)[1]
+        rng = np.random.default_rng(1)
+        for t in range(3):
+            flat = np.zeros(n_arena, np.float32)
+            grads = {}
+            for n in names:
+                g = (rng.standard_normal(P[n].shape) * 10.0 ** rng.uniform(-6, 0)).astype(np.float32)
+                g[rng.uniform(size=g.shape) < 0.05] = 0.0            # exact zeros: 0 / (0 + eps) must stay 0
+                grads[n] = g
+                off, size = table[n]
+                flat[off:off + size] = g.reshape(-1)
+            eng.set_arena(net, _lib.ARENA_GRADS, flat)
+            eng.apply_adam(net)
+            opt.apply(P, grads)
+            assert eng.adam_step(net) == t + 1
+            W = eng.get_weights(net)
+            m, v = eng.get_adam_state(net)
+            for n in names:
+                # one fp32 rounding per operation on both sides; lr_t * g / sqrt(v) <= lr / sqrt(1 - b2) per step
+                assert float(np.abs(W[n] - P[n]).max()) <= 2e-3 * 1e-4, (net, t, n)
+                np.testing.assert_allclose(v[n], opt.v[n], rtol=2e-6, atol=0)
+                np.testing.assert_allclose(m[n], opt.m[n], rtol=2e-6, atol=1e-30)
+        eng.close()
+
+
+def _masked_weight_check(W, W0, Wref, G_list, lr, what):
+    """Weights after several Adam steps vs the oracle on the elements whose oracle gradient was never rounding-sized
+    (>= 5 % of the tensor's rms at every step), and the whole displacement in relative L2."""
+    num = den = 0.0
+    worst = 0.0
+    for k in Wref:
+        d, dref = W[k].astype(np.float64) - W0[k], Wref[k].astype(np.float64) - W0[k]
+        num += float(((d - dref) ** 2).sum())
+        den += float((dref ** 2).sum())
+        mask = np.ones(W0[k].shape, bool)
+        for G in G_list:
+            g = np.abs(G[k])
+            mask &= g >= 0.05 * (np.sqrt((g ** 2).mean()) + 1e-30)
+        if mask.any():
+            worst = max(worst, float(np.abs(d - dref)[mask].max()))
+    l2 = np.sqrt(num / max(den, 1e-300))
+    print("%s: displacement rel-L2 %.3e, worst masked |dw| error %.3e lr" % (what, l2, worst / lr))
+    return l2, worst / lr
+
+
+@pytest.mark.parametrize("which", ["D_y2", "D_dem", "G"])
+def test_three_step_trajectory_vs_fp64_oracle(lib, which):
+    """Three updates of one network on three different tie-free batches: per-step outputs, Adam v and m after the
+    third step, and the weights, against the fp64 oracle (GT:549 / 568 / 594)."""
+    from oracle import depgan_oracle as O
+    img, B, lr = 64, 2, 1e-4
+    PG, PD1, PD2, x, y2, z, ep = _setup(img, B, 131, nb=3)
+    tr, nets = _trainers(img, B, PG, PD1, PD2)
+    ref = O.OracleTrainers({k: v.copy() for k, v in PG.items()}, {k: v.copy() for k, v in PD1.items()},
+                           {k: v.copy() for k, v in PD2.items()}, dtype=torch.float64)
+    P0 = {"G": PG, "D_y2": PD1, "D_dem": PD2}[which]
+    opt = {"G": ref.optG, "D_y2": ref.optD_y2, "D_dem": ref.optD_dem}[which]
+    G_list = []
+    for t in range(3):
+        s = slice(t * B, (t + 1) * B)
+        if which == "G":
+            got, want = tr.netG_train([x[s], y2[s], z[s]]), ref.netG_train([x[s], y2[s], z[s]])
+        else:
+            name = "netD_y2_train" if which == "D_y2" else "netD_dem_train"
+            got = getattr(tr, name)([y2[s], x[s], z[s], ep[s]])
+            want = getattr(ref, name)([y2[s], x[s], z[s], ep[s]])
+        # steps 2 and 3 are evaluated at weights that already moved: a wrong update shows up here
+        assert srel(got, want) < (1e-3 if t == 0 else 3e-3), (which, t, got, want)
+        G_list.append({k: np.asarray(v, np.float64) for k, v in opt.m.items()})       # beta1 = 0: m is the gradient
+    assert tr.engine.adam_step(which) == 3
+    m, v = tr.engine.get_adam_state(which)
+    Wref = {"G": ref._PG, "D_y2": ref._PDy2, "D_dem": ref._PDdem}[which]
+    names = O.trainable_names(P0)
+    worst_v = max(rel(v[k], opt.v[k]) for k in names)
+    worst_m = max(rel(m[k], opt.m[k]) for k in names)
+    print("%s: v rel %.3e, m rel %.3e" % (which, worst_v, worst_m))
+    # v = sum_t 0.1 * 0.9^(3-t) g_t^2 is smooth in the gradients: 2x the gradient tolerance (it is quadratic), with the
+    # sign-flip slack of steps 2-3 seeing slightly different weights
+    assert worst_v < 1e-2, worst_v
+    assert worst_m < 5e-3, worst_m
+    W = tr.engine.get_weights(which)
+    l2, worst = _masked_weight_check(W, P0, Wref, G_list, lr, which)
+    assert max(float(np.abs(W[k] - Wref[k]).max()) for k in names) <= 2.0 * lr * 3 * 1.05    # never more than 3 flips
+    assert worst < 0.25, worst          # elements with a real gradient: within a quarter of one step after three
+    assert l2 < 0.35, l2
+
+
+def test_tie_free_256_gradients_1e3(lib):
+    """The 1e-3 gradient check at the BASELINE resolution (256x256, batch 2, tie-free inputs): both critics (first
+    order + gradient-penalty double backward) and the generator, every tensor, against the fp64 oracle."""
+    from dep_gan_im_amd import Engine
+    from oracle import depgan_oracle as O
+    img, B = 256, 2
+    PG, PD1, PD2, x, y2, z, ep = _setup(img, B, 231)
+    eng = Engine(B, img, img, 1)
+    for n, P in (("G", PG), ("D_y2", PD1), ("D_dem", PD2)):
+        eng.set_weights(n, P)
+    rows = []
+    for which, PD, key in (("D_y2", PD1, "y2"), ("D_dem", PD2, "dem")):
+        out = eng.critic(which, y2, x, z, ep, update=False)
+        outs, g64, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float64)
+        _, g32, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float32)
+        assert srel(out, outs) < 1e-3
+        gg = eng.get_grads(which)
+        worst = max(rel(gg[k], g64[k]) for k in g64)
+        l2 = np.sqrt(sum(((gg[k] - g64[k]) ** 2).sum() for k in g64) / sum((g64[k] ** 2).sum() for k in g64))
+        o32 = max(rel(g32[k], g64[k]) for k in g64)
+        rows.append((which, worst, l2, o32))
+        assert worst < 1e-3, (which, worst)
+        assert l2 < 1e-3
+    out = eng.generator(x, y2, z, "grads")
+    outs, g64 = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float64)
+    _, g32 = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float32)
+    assert srel(out, outs) < 1e-3
+    gg = eng.get_grads("G")
+    worst = max(rel(gg[k], g64[k]) for k in g64)
+    l2 = np.sqrt(sum(((gg[k] - g64[k]) ** 2).sum() for k in g64) / sum((g64[k] ** 2).sum() for k in g64))
+    o32 = max(rel(g32[k], g64[k]) for k in g64)
+    rows.append(("G", worst, l2, o32))
+    for r in rows:
+        print("tie-free 256x256 %s: HIP-vs-fp64 max-rel %.2e, whole-gradient rel-L2 %.2e; oracle fp32-vs-fp64 %.2e" % r)
+    # the generator gradient passes through both critics' kinks; whole-gradient L2 at 1e-3, per tensor at 2e-3 or the
+    # oracle's own fp32 spread
+    assert l2 < 1e-3
+    assert worst < max(2e-3, 3 * o32), (worst, o32)
+    eng.close()
+
+
+def test_fused_generator_iteration_equals_closure_schedule(lib):
+    """depgan_gen_iteration (one enqueue, one host synchronisation, device-side arg-min) against the same generator
+    iterations driven closure by closure: identical scalars, identical noise choice, identical weights and Adam state
+    (same kernels in the same order on the same inputs -> bitwise)."""
+    from dep_gan_im_amd.schedule import ScheduleState, train_epoch
+    img, B = 64, 2
+    PG, PD1, PD2, x, y2, z, ep = _setup(img, B, 171, nb=7)
+    logs, weights, adam = [], [], []
+    for fused in (False, True):
+        tr, nets = _trainers(img, B, PG, PD1, PD2)
+        st = ScheduleState()
+        st.gen_iterations = 40                               # steady state: Diters critic steps per loop
+        log = []
+        xd, yd = (torch.from_numpy(x).cuda(), torch.from_numpy(y2).cuda()) if fused else (x, y2)
+        train_epoch(tr, xd, yd, batchSize=B, Diters=3, k_noise=4, state=st, rng=np.random.RandomState(9),
+                    on_gen_iteration=log.append, fused=fused)
+        logs.append(log)
+        weights.append([n.get_weights_dict() for n in nets])
+        adam.append([tr.engine.get_adam_state(n) for n in ("G", "D_y2", "D_dem")])
+        assert [tr.engine.adam_step(n) for n in ("G", "D_y2", "D_dem")] == [3, 7, 7]
+        tr.engine.close()
+    assert len(logs[0]) == len(logs[1]) == 3               # 7 batches, Diters 3: critic loops of 3, 3, 1
+    for a, b in zip(*logs):
+        assert a["best_noise"] == b["best_noise"] and (a["i"], a["ii"]) == (b["i"], b["ii"])
+        for k in ("errD_real", "errD_fake", "errD_real_dem", "errD_fake_dem", "errG", "errG_CY2", "errG_DEM",
+                  "errG_MSE", "errG_VOL", "errG_WMH"):
+            assert a[k] == b[k], (k, a[k], b[k])
+        assert a["losses_errG"] == b["losses_errG"]
+    for wa, wb in zip(*weights):
+        for k in wa:
+            np.testing.assert_array_equal(wa[k], wb[k])
+    for (ma, va), (mb, vb) in zip(*adam):
+        for k in ma:
+            np.testing.assert_array_equal(ma[k], mb[k])
+            np.testing.assert_array_equal(va[k], vb[k])
+
+
+def test_gen_iteration_argument_checks(lib):
+    from dep_gan_im_amd import Engine
+    eng = Engine(2, 64, 64, 1)
+    x = np.zeros((4, 64, 64, 1), np.float32)
+    z, ep = np.zeros((2, 2, 32, 1), np.float32), np.zeros((2, 2, 1, 1, 1), np.float32)
+    zs = np.zeros((3, 2, 32, 1), np.float32)
+    with pytest.raises(ValueError):                          # three batches asked of a two-batch array
+        eng.gen_iteration((x, x, np.zeros((3, 2, 32, 1)), np.zeros((3, 2)), 3), (x, x, z, ep, 2), (x[:2], x[:2], zs))
+    with pytest.raises(ValueError):
+        eng.gen_iteration((x, x, z, ep, 2), (x, x, z, ep, 2), (x[:2], x[:2], np.zeros((40, 2, 32, 1))))
+    cy, cd, ev, tr, best = eng.gen_iteration((None, None, None, None, 0), (x, x, z, ep, 2), (x[:2], x[:2], zs))
+    assert cy == [] and len(cd) == 2 and len(ev) == 3 and len(tr) == 6 and 0 <= best < 3
+    eng.close()
+
+
+def test_training_state_checkpoint_resume_is_bit_identical(lib, tmp_path):
+    """Two generator iterations, save_state, load into a FRESH context, third iteration: the resumed run must be
+    bitwise the uninterrupted one (three networks, BN statistics, Adam m / v / iterations, schedule counters)."""
+    import dep_gan_im_amd as dg
+    from dep_gan_im_amd.schedule import ScheduleState, train_epoch
+    img, B = 64, 2
+    PG, PD1, PD2, x, y2, z, ep = _setup(img, B, 191, nb=6)
+
+    def run(tr, st, lo, hi, seed):
+        log = []
+        train_epoch(tr, x[lo * B:hi * B], y2[lo * B:hi * B], batchSize=B, Diters=2, k_noise=3, state=st,
+                    rng=np.random.RandomState(seed), on_gen_iteration=log.append, shuffle=False)
+        return log
+
+    tr, nets = _trainers(img, B, PG, PD1, PD2)
+    st = ScheduleState()
+    st.gen_iterations = 50
+    run(tr, st, 0, 4, 1)                                     # two generator iterations (2 + 2 critic batches)
+    path = str(tmp_path / "state.npz")
+    tr.save_state(path, st)
+    log_a = run(tr, st, 4, 6, 2)                             # the third, uninterrupted
+    wa = [n.get_weights_dict() for n in nets]
+    # resume: fresh models with OTHER weights, fresh engine, fresh counters
+    nets2 = [dg.Gen_UNet2D((img, img, 1), seed=5), dg.Dis_C2D_FCN1((img, img, 1), seed=6),
+             dg.Dis_C2D_FCN1((img, img, 1), seed=7)]
+    tr2 = dg.build_trainers(*nets2, batchSize=B)
+    st2 = ScheduleState()
+    tr2.load_state(path, st2)
+    assert (st2.gen_iterations, st2.crit_iterations, st2.crit_dem_iterations) == (52, 4, 4)
+    assert [tr2.engine.adam_step(n) for n in ("G", "D_y2", "D_dem")] == [2, 4, 4]
+    log_b = run(tr2, st2, 4, 6, 2)
+    assert len(log_a) == len(log_b) == 1
+    for k in log_a[0]:
+        assert log_a[0][k] == log_b[0][k], k
+    for w1, n2 in zip(wa, nets2):
+        w2 = n2.get_weights_dict()
+        for k in w1:
+            np.testing.assert_array_equal(w1[k], w2[k])
+    with pytest.raises(KeyError):
+        d = tr.state_dict()
+        d.pop("G/weights/conv2d_gen_0/kernel")
+        tr2.load_state(d)
+
+
+def test_config4_full_size_nicg2_bf16_weights_batch32(lib):
+    """BASELINE configs[3] at its own size (256x256x2, batch 32, bf16 weights / fp32 accumulate): one critic-Y2 update
+    against the fp64 oracle at round_kernels_bf16(weights) (a full batch-32 oracle step: ~10 s of CPU), the generator
+    forward on the first two samples, sample independence of the forward pass (batch 32 = 4 x batch 8, bitwise) and
+    run-to-run bit reproducibility of the gradients."""
+    from dep_gan_im_amd import Engine
+    from oracle import depgan_oracle as O
+    img, B = 256, 32
+    PG = O.init_generator(23, nicg=2, bias_std=0.05)
+    PD1 = O.init_critic(24, bias_std=0.05, img=img)
+    PD2 = O.init_critic(25, bias_std=0.05, img=img)
+    x, y2, z, ep = O.synth_batch(26, B, img, img, nicg=2)
+    eng = Engine(B, img, img, 2, bf16_weights=True)
+    for n, P in (("G", PG), ("D_y2", PD1), ("D_dem", PD2)):
+        eng.set_weights(n, P)
+    attr = eng.g_forward(x, z).cpu().numpy()
+    np.testing.assert_allclose(attr[:2], O.g_predict(O.round_kernels_bf16(PG), x[:2], z[:2], nicg=2), rtol=1e-3,
+                               atol=1e-4)
+    out = eng.critic("D_y2", y2, x, z, ep, update=False)
+    g1 = eng.get_grads("D_y2")
+    gp = eng.last_sums()[2] / eng.last_sums()[3]
+    outs, g64, aux = O.critic_grads(O.round_kernels_bf16(PD1), O.round_kernels_bf16(PG), y2, x, z, ep, "y2", nicg=2,
+                                    dtype=torch.float64)
+    assert srel(out, outs) < 1e-3, (out, outs)
+    assert abs(gp - float(aux["gp"])) < 1e-3 * (abs(float(aux["gp"])) + 1e-3)
+    l2 = np.sqrt(sum(((g1[k] - g64[k]) ** 2).sum() for k in g64) / sum((g64[k] ** 2).sum() for k in g64))
+    print("config 4 @ 256x256x2 b32: critic-Y2 whole-gradient rel-L2 vs fp64 oracle %.3e" % l2)
+    assert l2 < 5e-2        # reference-like (flat-region) inputs: the oracle's own fp32-vs-fp64 spread is 1-4 %
+    eng.critic("D_y2", y2, x, z, ep, update=False)
+    g2 = eng.get_grads("D_y2")
+    assert all(np.array_equal(g1[k], g2[k]) for k in g1)
+    ev = eng.generator(x, y2, z, "grads")
+    sums = eng.last_sums()
+    eng.close()
+    small = Engine(8, img, img, 2, bf16_weights=True)
+    for n, P in (("G", PG), ("D_y2", PD1), ("D_dem", PD2)):
+        small.set_weights(n, P)
+    acc = np.zeros(8)
+    for i in range(0, B, 8):
+        s = slice(i, i + 8)
+        np.testing.assert_array_equal(small.g_forward(x[s], z[s]).cpu().numpy(), attr[s])
+        small.generator(x[s], y2[s], z[s], "eval")
+        acc += np.array(small.last_sums())
+    small.close()
+    np.testing.assert_allclose(acc, sums, rtol=2e-5)
+
+
+def test_config5_full_size_uresnet_batch32(lib):
+    """BASELINE configs[4] at its own size (DEP-UResNet, 256x256, batch 32, learning phase 1): loss, whole-gradient
+    L2 and the BN moving statistics of one train_on_batch against the oracle on the full batch (batch statistics tie
+    the samples together, so there is no smaller proxy), bit reproducibility, and phase-0 predict independence."""
+    import dep_gan_im_amd as dg
+    from oracle import depgan_oracle as O
+    img, B = 256, 32
+    P = O.init_generator(33, nc_out=4, bias_std=0.05)
+    x, z, lab = O.synth_uresnet_batch(34, B, img, img)
+    nets = []
+    losses = []
+    for _ in range(2):
+        net = dg.Gen_UNet2D((img, img, 1), (32, 1), 32, 4)
+        net.set_weights({k: v.copy() for k, v in P.items()})
+        losses.append(net.train_on_batch([x, z], lab, drop_seed=77))
+        nets.append(net)
+    assert losses[0] == losses[1]
+    w0, w1 = nets[0].get_weights_dict(), nets[1].get_weights_dict()
+    assert all(np.array_equal(w0[k], w1[k]) for k in w0)                      # bitwise reproducible
+    ref = O.OracleUResNet({k: v.copy() for k, v in P.items()}, dtype=torch.float32)
+    want = ref.train_on_batch([x, z], lab, drop_seed=77)
+    assert abs(losses[0] - want) < 1e-3 * abs(want), (losses[0], want)
+    for k in w0:
+        if k.endswith("moving_mean") or k.endswith("moving_variance"):
+            np.testing.assert_allclose(w0[k], ref.P[k], rtol=1e-3, atol=1e-5, err_msg=k)
+    # first Adam step: +-lr per element; what is compared is the direction, through the whole displacement
+    num = sum(float(((w0[k].astype(np.float64) - ref.P[k]) ** 2).sum()) for k in O.trainable_names(P))
+    den = sum(float(((ref.P[k].astype(np.float64) - P[k]) ** 2).sum()) for k in O.trainable_names(P))
+    print("config 5 @ 256x256 b32: loss %.6f vs %.6f, displacement rel-L2 %.3e" % (losses[0], want, np.sqrt(num / den)))
+    assert np.sqrt(num / den) < 0.5
+    p32 = nets[0].predict([x, z], batch_size=32)
+    p8 = np.concatenate([nets[1].predict([x[i:i + 8], z[i:i + 8]], batch_size=8) for i in range(0, B, 8)])
+    np.testing.assert_array_equal(p32, p8)
+    np.testing.assert_allclose(p32[:2], ref.predict([x[:2], z[:2]]), rtol=1e-3, atol=1e-4)
