@@ -302,16 +302,20 @@ class KerasAdam:
         self.v = {}
 
     def apply(self, P, grads):
-        """P: dict name->np array (updated in place); grads: dict name->np array."""
+        """P: dict name->np array (updated in place); grads: dict name->np array.
+        beta_1 / beta_2 are float32 backend variables in Keras, so `1. - self.beta_2` is a float32 subtraction
+        (1 - 0.999f, not float32(0.001)); the moments follow in float32."""
         t = self.iterations + 1
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
         for n in self.names:
+            dt = P[n].dtype.type
+            b1, b2, one = dt(self.b1), dt(self.b2), dt(1.0)
             g = np.asarray(grads[n], dtype=P[n].dtype)
             m = self.m.get(n, np.zeros_like(P[n]))
             v = self.v.get(n, np.zeros_like(P[n]))
-            m = self.b1 * m + (1.0 - self.b1) * g
-            v = self.b2 * v + (1.0 - self.b2) * g * g
-            P[n] = (P[n] - lr_t * m / (np.sqrt(v) + self.eps)).astype(P[n].dtype)
+            m = b1 * m + (one - b1) * g
+            v = b2 * v + (one - b2) * g * g
+            P[n] = (P[n] - dt(lr_t) * m / (np.sqrt(v) + dt(self.eps))).astype(P[n].dtype)
             self.m[n], self.v[n] = m, v
         self.iterations = t
 

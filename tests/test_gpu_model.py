@@ -286,15 +286,17 @@ def test_reference_schedule_one_generator_iteration(lib):
         log = []
         train_epoch(t, x, y2, batchSize=B, Diters=1, state=st, rng=np.random.RandomState(5), on_gen_iteration=log.append)
         logs.append(log)
-    a, b = logs[0][0], logs[1][0]
-    assert a["Diters"] == 1 and len(logs[0]) == 2
-    for k in ("errD_real", "errD_fake", "errD_real_dem", "errD_fake_dem"):
-        assert abs(a[k] - b[k]) < 1e-3 * (abs(b[k]) + 1e-3), k
-    np.testing.assert_allclose(a["losses_errG"], b["losses_errG"], rtol=3e-3)
-    gap = np.sort(b["losses_errG"])
-    if gap[1] - gap[0] > 6e-3 * abs(gap[0]):
-        assert a["best_noise"] == b["best_noise"]
-    assert abs(a["errG"] - b["errG"]) < 3e-3 * abs(b["errG"])
+    assert logs[0][0]["Diters"] == 1 and len(logs[0]) == len(logs[1]) == 2
+    # the second generator iteration runs on weights that all three networks' first updates produced
+    for it, tol in ((0, 1e-3), (1, 5e-3)):
+        a, b = logs[0][it], logs[1][it]
+        for k in ("errD_real", "errD_fake", "errD_real_dem", "errD_fake_dem"):
+            assert abs(a[k] - b[k]) < tol * (abs(b[k]) + 1e-3), (it, k, a[k], b[k])
+        np.testing.assert_allclose(a["losses_errG"], b["losses_errG"], rtol=3 * tol)
+        gap = np.sort(b["losses_errG"])
+        if gap[1] - gap[0] > 6 * tol * abs(gap[0]):
+            assert a["best_noise"] == b["best_noise"]
+        assert abs(a["errG"] - b["errG"]) < 3 * tol * abs(b["errG"])
 
 
 def test_best_of_k_multi_eval_equals_k_single_evals(lib):

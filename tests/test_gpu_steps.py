@@ -27,8 +27,16 @@ def srel(got, want):
     return max(abs(a - b) / (abs(b) + 1e-3) for a, b in zip(got, want))
 
 
-def _setup(img, B, seed, nb=1):
-    """Tie-free (noisy) inputs: nb batches of B samples."""
+def _setup(img, B, seed, nb=1, trained_regime=True):
+    """Tie-free (noisy) inputs: nb batches of B samples.
+
+    trained_regime: WGAN-GP training drives the critic's input-gradient norm to 1; at random initialisation it is
+    ~0.005-0.01, where the penalty's gradient 2 delta (norm - 1) / norm * d norm amplifies every rounding error of the
+    first backward pass by ~1/norm: measured on these inputs at 256x256 (tools/diag_critic_sensitivity.py) a 1e-6
+    relative perturbation of the INPUT moves the fp64 gradient by up to 3e-3, and the oracle's own fp32 run is 1e-2 from
+    its fp64 run -- no fp32 implementation can meet 1e-3 there.  So the critics' last layer (dense_1, linear in the
+    output) is rescaled until the norm is ~2, the regime the reference actually trains in; everything upstream of it
+    keeps its initialisation."""
     from oracle import depgan_oracle as O
     PG = O.init_generator(seed, bias_std=0.05)
     PD1 = O.init_critic(seed + 1, bias_std=0.05, img=img)
@@ -37,6 +45,10 @@ def _setup(img, B, seed, nb=1):
     rng = np.random.default_rng(seed)
     x = (x + 0.02 * rng.uniform(size=x.shape)).astype(np.float32)
     y2 = (y2 + 0.02 * rng.uniform(size=y2.shape)).astype(np.float32)
+    if trained_regime:
+        for PD, key in ((PD1, "y2"), (PD2, "dem")):
+            _, _, aux = O.critic_grads(PD, PG, y2[:B], x[:B], z[:B], ep[:B], key, dtype=torch.float32)
+            PD["dense_1/kernel"] = (PD["dense_1/kernel"] * np.float32(2.0 / float(np.mean(aux["norm"])))).astype(np.float32)
     return PG, PD1, PD2, x, y2, z, ep
 
 
@@ -149,8 +161,9 @@ def test_three_step_trajectory_vs_fp64_oracle(lib, which):
 
 
 def test_tie_free_256_gradients_1e3(lib):
-    """The 1e-3 gradient check at the BASELINE resolution (256x256, batch 2, tie-free inputs): both critics (first
-    order + gradient-penalty double backward) and the generator, every tensor, against the fp64 oracle."""
+    """The 1e-3 gradient check at the BASELINE resolution (256x256, batch 2, tie-free inputs, critics in the trained
+    regime of the penalty -- see _setup): both critics (first order + gradient-penalty double backward) and the
+    generator, every tensor, against the fp64 oracle; the oracle's own fp32-vs-fp64 difference is printed next to it."""
     from dep_gan_im_amd import Engine
     from oracle import depgan_oracle as O
     img, B = 256, 2
@@ -158,34 +171,72 @@ def test_tie_free_256_gradients_1e3(lib):
     eng = Engine(B, img, img, 1)
     for n, P in (("G", PG), ("D_y2", PD1), ("D_dem", PD2)):
         eng.set_weights(n, P)
-    rows = []
-    for which, PD, key in (("D_y2", PD1, "y2"), ("D_dem", PD2, "dem")):
-        out = eng.critic(which, y2, x, z, ep, update=False)
-        outs, g64, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float64)
-        _, g32, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float32)
-        assert srel(out, outs) < 1e-3
-        gg = eng.get_grads(which)
+
+    def stats(gg, g64, g32):
         worst = max(rel(gg[k], g64[k]) for k in g64)
         l2 = np.sqrt(sum(((gg[k] - g64[k]) ** 2).sum() for k in g64) / sum((g64[k] ** 2).sum() for k in g64))
         o32 = max(rel(g32[k], g64[k]) for k in g64)
-        rows.append((which, worst, l2, o32))
-        assert worst < 1e-3, (which, worst)
-        assert l2 < 1e-3
+        o32l2 = np.sqrt(sum(((g32[k] - g64[k]) ** 2).sum() for k in g64) / sum((g64[k] ** 2).sum() for k in g64))
+        return worst, l2, o32, o32l2
+
+    rows = []
+    for which, PD, key in (("D_y2", PD1, "y2"), ("D_dem", PD2, "dem")):
+        out = eng.critic(which, y2, x, z, ep, update=False)
+        outs, g64, aux = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float64)
+        _, g32, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float32)
+        assert 1.0 < float(np.mean(aux["norm"])) < 4.0
+        assert srel(out, outs) < 1e-3
+        rows.append((which,) + stats(eng.get_grads(which), g64, g32))
     out = eng.generator(x, y2, z, "grads")
     outs, g64 = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float64)
     _, g32 = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float32)
     assert srel(out, outs) < 1e-3
-    gg = eng.get_grads("G")
-    worst = max(rel(gg[k], g64[k]) for k in g64)
-    l2 = np.sqrt(sum(((gg[k] - g64[k]) ** 2).sum() for k in g64) / sum((g64[k] ** 2).sum() for k in g64))
-    o32 = max(rel(g32[k], g64[k]) for k in g64)
-    rows.append(("G", worst, l2, o32))
+    rows.append(("G",) + stats(eng.get_grads("G"), g64, g32))
     for r in rows:
-        print("tie-free 256x256 %s: HIP-vs-fp64 max-rel %.2e, whole-gradient rel-L2 %.2e; oracle fp32-vs-fp64 %.2e" % r)
-    # the generator gradient passes through both critics' kinks; whole-gradient L2 at 1e-3, per tensor at 2e-3 or the
-    # oracle's own fp32 spread
-    assert l2 < 1e-3
-    assert worst < max(2e-3, 3 * o32), (worst, o32)
+        print("tie-free 256x256 %s: HIP-vs-fp64 max-rel %.2e, whole-gradient rel-L2 %.2e; oracle fp32-vs-fp64 %.2e / %.2e"
+              % r)
+    for which, worst, l2, o32, o32l2 in rows:
+        assert l2 < 1e-3, (which, l2)
+        assert worst < max(1e-3, 3 * o32), (which, worst, o32)
+    eng.close()
+
+
+def test_reference_like_256_gradients_relative_l2(lib):
+    """Reference-like inputs (exactly flat regions outside the brain mask: max-pool ties, ReLU kinks) at 256x256, critics
+    at their random initialisation (penalty ill-conditioned, see _setup): whole-gradient relative L2 of HIP vs the fp64
+    oracle, with the oracle's own fp32-vs-fp64 L2 as yardstick, and the measured conditioning -- the fp64 gradient's
+    response to a 1e-6 relative perturbation of the input -- printed for DESIGN.md."""
+    from dep_gan_im_amd import Engine
+    from oracle import depgan_oracle as O
+    img, B, seed = 256, 2, 3
+    PG = O.init_generator(seed, bias_std=0.05)
+    PD1 = O.init_critic(seed + 1, bias_std=0.05, img=img)
+    PD2 = O.init_critic(seed + 2, bias_std=0.05, img=img)
+    x, y2, z, ep = O.synth_batch(seed + 5, B, img, img)
+    eng = Engine(B, img, img, 1)
+    for n, P in (("G", PG), ("D_y2", PD1), ("D_dem", PD2)):
+        eng.set_weights(n, P)
+
+    def l2(a, b):
+        return float(np.sqrt(sum(((a[k] - b[k]) ** 2).sum() for k in b) / sum((b[k] ** 2).sum() for k in b)))
+
+    for which, PD, key in (("D_y2", PD1, "y2"), ("D_dem", PD2, "dem")):
+        eng.critic(which, y2, x, z, ep, update=False)
+        gg = eng.get_grads(which)
+        _, g64, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float64)
+        _, g32, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float32)
+        y2p = (y2.astype(np.float64) * (1 + 1e-6)).astype(np.float32)
+        _, gpert, _ = O.critic_grads(PD, PG, y2p, x, z, ep, key, dtype=torch.float64)
+        e_hip, e_o32, e_pert = l2(gg, g64), l2(g32, g64), l2(gpert, g64)
+        print("reference-like 256x256 %s: rel-L2 HIP-vs-fp64 %.2e, oracle fp32-vs-fp64 %.2e, fp64 under a 1e-6 input "
+              "perturbation %.2e" % (which, e_hip, e_o32, e_pert))
+        assert e_hip < 3.0 * e_o32 + 1e-3, (which, e_hip, e_o32)
+    eng.generator(x, y2, z, "grads")
+    gg = eng.get_grads("G")
+    _, g64 = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float64)
+    _, g32 = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float32)
+    print("reference-like 256x256 G: rel-L2 HIP-vs-fp64 %.2e, oracle fp32-vs-fp64 %.2e" % (l2(gg, g64), l2(g32, g64)))
+    assert l2(gg, g64) < 3.0 * l2(g32, g64) + 1e-3
     eng.close()
 
 

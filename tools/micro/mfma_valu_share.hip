@@ -27,14 +27,23 @@ __global__ __launch_bounds__(512) void k(int mode, int iters, float* out, unsign
   } else {
     float v = threadIdx.x, w = 1.0001f;
     int n = iters * 16;
+    // modes 5 / 6: the VALU chain of mode 1 at raised priority (5), or with the MFMA waves being the YOUNGER ones is not
+    // expressible here -- instead mode 6 runs the chain in short bursts separated by s_sleep, to see whether a prioritised
+    // wave's VALU instructions cut into another wave's fp32 MFMA stream at all
+    if (mode == 5 || mode == 6) __builtin_amdgcn_s_setprio(3);
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-    if (mode == 1) {
+    if (mode == 1 || mode == 5) {
       for (int i = 0; i < n; ++i) { v = fmaf(v, w, 1.0f); v = fmaf(v, w, 2.0f); v = fmaf(v, w, 3.0f); v = fmaf(v, w, 4.0f); }
     } else if (mode == 2) {
       int idx = threadIdx.x & 1023;
       for (int i = 0; i < n; ++i) { v += lds[idx]; idx = (idx + 64) & 4095; }
     } else if (mode == 3) {
       for (int i = 0; i < n / 8; ++i) sink[(size_t)blockIdx.x * 65536 + ((i * 512 + threadIdx.x) & 65535)] = v;
+    } else if (mode == 6) {
+      for (int i = 0; i < n / 64; ++i) {
+        for (int j = 0; j < 16; ++j) { v = fmaf(v, w, 1.0f); v = fmaf(v, w, 2.0f); v = fmaf(v, w, 3.0f); v = fmaf(v, w, 4.0f); }
+        __builtin_amdgcn_s_sleep(8);
+      }
     } else if (mode == 4) {
       unsigned u = threadIdx.x;
       for (int i = 0; i < n; ++i) { u = u * 1664525u + 1013904223u; u ^= u >> 7; u += i; u = (u << 3) | (u >> 29); }
@@ -48,7 +57,7 @@ int main() {
   float *out, *sink; unsigned long long *cyc, *cyc2;
   hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8); hipMalloc(&cyc2, 256 * 8); hipMalloc(&sink, (size_t)256 * 65536 * 4);
   const int iters = 4000;
-  for (int mode = 0; mode <= 4; ++mode) {
+  for (int mode = 0; mode <= 6; ++mode) {
     double res[2] = {0, 0}, co[2] = {0, 0};
     for (int on = 1; on >= 0; --on) {
       for (int rep = 0; rep < 2; ++rep) {
