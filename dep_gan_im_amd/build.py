@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdepgan.so")
-SOURCES = ["igemm_conv.hip", "wgrad.hip", "direct.hip", "ops.hip", "noise.hip", "train_ops.hip", "model.hip",
+SOURCES = ["igemm_conv.hip", "igemm_bf16.hip", "wgrad.hip", "direct.hip", "ops.hip", "noise.hip", "train_ops.hip", "model.hip",
            "uresnet.hip", "data.hip"]
 ARCH = "gfx950"
 
@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
 
 
 def _build_locked(force, verbose):
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "depgan.h"))
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)

@@ -138,10 +138,17 @@ struct ConvPlan {
   int NT;    // output channels per workgroup
   int CK;    // input channels staged per LDS chunk
   int nNT, nCC;
-  size_t packedFloats;
+  size_t packedFloats;  // size of the packed panel in 4-byte units (bf16 plans: two elements per unit)
   int variant;  // index into the instantiation table, -1 = not MFMA-eligible
+  int bf16;     // 1: bf16 matrix pipe (igemm_bf16.hip): panels are packed as bf16, the activation operand is rounded to
+                // bf16 while it is staged, accumulation stays fp32
 };
 ConvPlan dg_plan_conv(int KS, int Cin, int Cout);
+// the bf16 plan where the bf16 kernel covers the shape (Cout % 32 == 0, Cin >= 8), else the fp32 plan
+ConvPlan dg_plan_conv_bf16(int KS, int Cin, int Cout);
+int dg_conv_igemm_bf16(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
+// byte size of one packed element of a plan
+static inline size_t dg_plan_elem_bytes(const ConvPlan& pl) { return pl.bf16 ? 2 : 4; }
 
 // One weight-packing job of a batched launch (dg_pack_weights_batch): what dg_pack_weights takes, plus an optional
 // re-spacing of the channel-tile blocks in the destination (nt_stride elements between consecutive channel tiles;
@@ -152,7 +159,8 @@ struct PackJob {
   const float* kscale;
   int ntaps, srcI, srcO, io, transpose, flip;
   int NT, CK, nCC, Kdim, Ndim;
-  unsigned total;       // packed floats of this job
+  int bf16;             // 1: dst is a bf16 panel (elements of 2 bytes, RNE from the fp32 source x kscale)
+  unsigned total;       // packed elements of this job
   unsigned per_nt;      // packed floats per channel tile (nCC * ntaps * NT * CK)
   unsigned nt_stride;   // destination elements between channel tiles
   unsigned blk0, nblk;  // first block and number of blocks of this job inside the batched grid

@@ -22,6 +22,12 @@
 #include "common.h"
 #include "epilogue.h"
 
+// one packed weight element: fp32, or bf16 (RNE; plain cast = v_cvt_pk_bf16_f32) for the bf16 matrix pipe
+__device__ __forceinline__ void store_packed(float* dst, size_t i, float v, int bf16) {
+  if (bf16) reinterpret_cast<__bf16*>(dst)[i] = (__bf16)v;
+  else dst[i] = v;
+}
+
 template <int MF>
 struct Mfma;
 template <>
@@ -316,152 +322,7 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_ker
   }
 
   if (dbg && tid == 0) dbg[4] = __builtin_amdgcn_s_memtime();
-  // ---- epilogue ----
-  // The CU retires only about one vector-memory wave-instruction per ~100 cycles here, so the
-  // store tail is as long as the MFMA phase unless every instruction covers whole lines.  Each wave's 64 x NT tile
-  // goes through LDS and is emitted as 16-byte accesses: 8 lanes x 16 B cover one pixel's 32 channels (one full
-  // 128-B line).  (Storing the quads straight from the accumulators -- 32 lines of 32 bytes per instruction -- was
-  // measured 3 % slower than this.)
-  __syncthreads();  // every wave is done with its fragment reads; the tile region is free
-  constexpr int CP = NT + 4;
-  float* es = smem + wv * (64 * CP);
-  // The MFMAs take the WEIGHT fragment as their first operand, so the accumulators hold the transposed tile
-  // D[channel][pixel]: lane (r, h) owns pixel r of each pixel tile and its registers 4g .. 4g+3 are four consecutive
-  // channels (8g + 4h + 0..3 of the 32x32 tile, 4h + 0..3 of the 16x16 one) -> one 16-byte LDS write per quad
-  // (rows of CP = NT + 4 floats: 8 consecutive lanes hit 8 different 16-byte bank groups).
-  constexpr int NQ = (MF == 32) ? 4 : 1, CSTEP = (MF == 32) ? 8 : 4;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int g = 0; g < NQ; ++g) {
-      f32x4 q4;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) q4[k] = acc[mt][4 * g + k];
-      *reinterpret_cast<f32x4*>(es + (MF * mt + r) * CP + CSTEP * g + 4 * h) = q4;
-    }
-  // On a SIMD nothing that is issued overlaps with fp32 MFMAs, so the epilogue is written for
-  // instruction count: every operand test is a scalar branch on a kernel argument, and every access is
-  // (uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset computed once) so that the loads and stores take the
-  // saddr form and the per-pass address arithmetic is a handful of scalar adds.
-  constexpr int LPP = NT / 4;     // lanes per pixel
-  constexpr int PPP = 64 / LPP;   // pixels per pass (8 for NT = 32: half a tile row; 16 for NT = 16: one row)
-  constexpr int NPASS = 64 / PPP;
-  const int c4 = (lane % LPP) * 4, pl0 = lane / LPP;
-  const int co = n0 + c4;
-  const int wvu = __builtin_amdgcn_readfirstlane(wv);
-  const Epilogue& e = a.ep;
-  const bool affine = e.scale != nullptr, film = e.film_mul != nullptr, relu = e.relu != 0, accum = e.accumulate != 0;
-  const bool has_bias = e.bias != nullptr, has_pre = e.out_pre.p != nullptr, has_res = e.res.p != nullptr,
-             has_msk = e.mask.p != nullptr, has_pool = e.pool.p != nullptr;
-  const int oyw = ty0 + 4 * wvu;
-  const bool full = (ty0 + 16 <= a.H) && (tx0 + 16 <= a.W);
-  if (co < a.Cout) {
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 fm4 = {1.f, 1.f, 1.f, 1.f}, fa4 = {0.f, 0.f, 0.f, 0.f};
-    if (has_bias) bias4 = *reinterpret_cast<const f32x4*>(e.bias + co);
-    if (affine) {
-      sc4 = *reinterpret_cast<const f32x4*>(e.scale + co);
-      sh4 = *reinterpret_cast<const f32x4*>(e.shift + co);
-    }
-    if (film) {
-      fm4 = *reinterpret_cast<const f32x4*>(e.film_mul + (long)b * e.film_ld + co);
-      fa4 = *reinterpret_cast<const f32x4*>(e.film_add + (long)b * e.film_ld + co);
-    }
-    // Buffer addressing: per view one resource descriptor (SGPRs) at pixel (oyw, tx0) of sample b, a per-lane byte
-    // offset computed once (pixel pl0 of the pass, channel co) and a scalar byte offset per pass -- the eight passes
-    // issue no address arithmetic on the vector ALU at all.
-    auto mk = [&](const float* p) {
-      // the descriptor must be wave-uniform: the pointer depends on the wave index
-      const unsigned long long u = (unsigned long long)p;
-      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-      return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7FFFFFFF, 0x00020000);
-    };
-    const int lo_out = 4 * (pl0 * (int)a.out.sX + co);
-    const int lo_pre = has_pre ? 4 * (pl0 * (int)e.out_pre.sX + co) : 0;
-    const int lo_res = has_res ? 4 * (pl0 * (int)e.res.sX + co) : 0;
-    const int lo_msk = has_msk ? 4 * (pl0 * (int)e.mask.sX + co) : 0;
-    const __amdgpu_buffer_rsrc_t r_out = mk(a.out.p + out_goff + view_off(a.out, b, oyw, tx0));
-    const __amdgpu_buffer_rsrc_t r_pre = mk(has_pre ? e.out_pre.p + view_off(e.out_pre, b, oyw, tx0) : a.out.p);
-    const __amdgpu_buffer_rsrc_t r_res = mk(has_res ? e.res.p + view_off(e.res, b, oyw, tx0) : a.out.p);
-    const __amdgpu_buffer_rsrc_t r_msk = mk(has_msk ? e.mask.p + view_off(e.mask, b, oyw, tx0) : a.out.p);
-    // fused 2x2 max-pool: the wave's 4 x 16 block holds whole pool windows (tile origins are multiples of 16); the
-    // two rows of a window are two passes apart, its two columns 8 lanes (NT = 32) or 4 lanes (NT = 16) apart
-    const __amdgpu_buffer_rsrc_t r_pool =
-        mk(has_pool ? e.pool.p + view_off(e.pool, b, oyw >> 1, tx0 >> 1) : a.out.p);
-    const int lo_pool = has_pool ? 4 * ((pl0 >> 1) * (int)e.pool.sX + co) : 0;
-    const int sY_pool = 4 * (int)e.pool.sY, sX_pool = 4 * (int)e.pool.sX;
-    f32x4 vrow = {0.f, 0.f, 0.f, 0.f};
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
-      const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-      return __builtin_bit_cast(f32x4, t);
-    };
-    auto st = [&](const __amdgpu_buffer_rsrc_t& r, int voff, int soff, f32x4 v) {
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, voff, soff, 0);
-    };
-    const int sY_out = 4 * (int)a.out.sY, sX_out = 4 * (int)a.out.sX;
-    const int sY_pre = 4 * (int)e.out_pre.sY, sX_pre = 4 * (int)e.out_pre.sX;
-    const int sY_res = 4 * (int)e.res.sY, sX_res = 4 * (int)e.res.sX;
-    const int sY_msk = 4 * (int)e.mask.sY, sX_msk = 4 * (int)e.mask.sX;
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-      // pass p covers pixels (py, px0 .. px0 + PPP) of the wave's 4 x 16 block; the passes walk the block so that
-      // the two rows of a 2x2 pool window are consecutive passes (row pair, then the next column part)
-      constexpr int RP = 16 / PPP;      // passes per pixel row
-      const int py = (p & 1) + 2 * (p / (2 * RP)), px0 = ((p >> 1) % RP) * PPP;
-      const bool ok = full || (oyw + py < a.H && tx0 + px0 + pl0 < a.W);
-      f32x4 v = *reinterpret_cast<const f32x4*>(es + (py * 16 + px0 + pl0) * CP + c4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        v[k] += bias4[k];
-        if (affine) v[k] = __fadd_rn(__fmul_rn(v[k], sc4[k]), sh4[k]);
-      }
-      if (has_pre) {
-        if (ok) st(r_pre, lo_pre, py * sY_pre + px0 * sX_pre, v);
-      }
-      if (film) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = film_preact(v[k], fm4[k], fa4[k]);
-      }
-      if (relu) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-      }
-      if (has_res) {
-        f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-        if (ok) rr = ld(r_res, lo_res, py * sY_res + px0 * sX_res);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += rr[k];
-      }
-      if (has_msk) {
-        f32x4 mm = {1.f, 1.f, 1.f, 1.f};
-        if (ok) mm = ld(r_msk, lo_msk, py * sY_msk + px0 * sX_msk);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (mm[k] > 0.f) ? v[k] : 0.f;
-      }
-      const int so = py * sY_out + px0 * sX_out;
-      if (accum) {
-        f32x4 old = {0.f, 0.f, 0.f, 0.f};
-        if (ok) old = ld(r_out, lo_out, so);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += old[k];
-      }
-      if (ok) st(r_out, lo_out, so, v);
-      if (has_pool) {
-        if ((py & 1) == 0) {
-          vrow = v;
-        } else {
-          f32x4 m;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float t = fmaxf(vrow[k], v[k]);
-            m[k] = fmaxf(t, __shfl_xor(t, LPP, 64));
-          }
-          if (ok && (pl0 & 1) == 0) st(r_pool, lo_pool, (py >> 1) * sY_pool + (px0 >> 1) * sX_pool, m);
-        }
-      }
-    }
-  }
+#include "igemm_epilogue.inc"
   if (dbg && tid == 0) {
     dbg[5] = __builtin_amdgcn_s_memtime();
     dbg[6] = __builtin_amdgcn_s_memrealtime() - dbg[6];
@@ -491,6 +352,7 @@ ConvPlan dg_plan_conv(int KS, int Cin, int Cout) {
   p.Cin = Cin;
   p.Cout = Cout;
   p.variant = -1;
+  p.bf16 = 0;
   p.MF = (Cout % 32 == 0) ? 32 : 16;
   p.NT = p.MF;
   p.CK = 16;
@@ -557,6 +419,7 @@ static int launch_variant(const ConvArgs& a, hipStream_t st) {
 
 int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
   ConvArgs a = a_in;
+  const bool is_bf16 = pl.bf16 != 0;
   if (pl.variant < 0) {
     dg_set_error("dg_conv_igemm: no MFMA variant for KS=%d Cin=%d Cout=%d", pl.KS, pl.Cin, pl.Cout);
     return DG_ERR_UNSUPPORTED;
@@ -582,6 +445,7 @@ int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
       return DG_ERR_ARG;
     }
   }
+  if (is_bf16) return dg_conv_igemm_bf16(pl, a, st);
   switch (pl.variant) {
     case 0: return launch_variant<32, 3, 16, 9>(a, st);
     case 1: return launch_variant<16, 3, 16, 9>(a, st);
@@ -598,7 +462,7 @@ int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
 // ---------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int ntaps, int srcI,
                                     int srcO, int io, int transpose, int flip, const float* __restrict__ kscale,
-                                    int NT, int CK, int nCC, int Kdim, int Ndim, size_t total) {
+                                    int NT, int CK, int nCC, int Kdim, int Ndim, size_t total, int bf16) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t q = i;
     const int k = (int)(q % CK);
@@ -619,7 +483,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
       v = src[off];
       if (kscale) v *= kscale[kk];
     }
-    dst[i] = v;
+    store_packed(dst, i, v, bf16);
   }
 }
 
@@ -653,21 +517,22 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackJob* 
       v = J.src[off];
       if (J.kscale) v *= J.kscale[kk];
     }
-    J.dst[(size_t)nt * J.nt_stride + (i - (unsigned)nt * J.per_nt)] = v;
+    store_packed(J.dst, (size_t)nt * J.nt_stride + (i - (unsigned)nt * J.per_nt), v, J.bf16);
   }
 }
 
 int dg_pack_job(const ConvPlan& pl, const float* src, int srcI, int srcO, int io, int transpose, int flip,
                 const float* kscale, float* dst, size_t nt_stride, PackJob* job) {
   const int Kdim = transpose ? srcO : srcI, Ndim = transpose ? srcI : srcO;
-  if (Kdim != pl.Cin || Ndim != pl.Cout || pl.variant < 0 || pl.packedFloats >= (1ull << 31)) {
+  if (Kdim != pl.Cin || Ndim != pl.Cout || pl.variant < 0 || pl.packedFloats >= (1ull << 30)) {
     dg_set_error("dg_pack_job: plan (%d->%d) does not match source roles (%d->%d)", pl.Cin, pl.Cout, Kdim, Ndim);
     return DG_ERR_ARG;
   }
   job->src = src; job->dst = dst; job->kscale = kscale;
   job->ntaps = pl.KS * pl.KS; job->srcI = srcI; job->srcO = srcO; job->io = io; job->transpose = transpose;
   job->flip = flip; job->NT = pl.NT; job->CK = pl.CK; job->nCC = pl.nCC; job->Kdim = Kdim; job->Ndim = Ndim;
-  job->total = (unsigned)pl.packedFloats;
+  job->bf16 = pl.bf16;
+  job->total = (unsigned)((size_t)pl.nNT * pl.nCC * pl.KS * pl.KS * pl.NT * pl.CK);
   job->per_nt = (unsigned)((size_t)pl.nCC * pl.KS * pl.KS * pl.NT * pl.CK);
   job->nt_stride = nt_stride ? (unsigned)nt_stride : job->per_nt;
   job->blk0 = job->nblk = 0;
@@ -701,10 +566,10 @@ int dg_pack_weights(const ConvPlan& pl, const float* src, int srcI, int srcO, in
     dg_set_error("dg_pack_weights: plan (%d->%d) does not match source roles (%d->%d)", pl.Cin, pl.Cout, Kdim, Ndim);
     return DG_ERR_ARG;
   }
-  const size_t total = pl.packedFloats;
+  const size_t total = (size_t)pl.nNT * pl.nCC * pl.KS * pl.KS * pl.NT * pl.CK;
   const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, st, src, dst, pl.KS * pl.KS, srcI, srcO, io,
-                     transpose, flip, kscale, pl.NT, pl.CK, pl.nCC, Kdim, Ndim, total);
+                     transpose, flip, kscale, pl.NT, pl.CK, pl.nCC, Kdim, Ndim, total, pl.bf16);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }

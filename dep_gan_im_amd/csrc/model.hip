@@ -96,6 +96,11 @@ static int net_requantize(depgan_ctx* c, Net& n) {
   return dg_round_bf16_masked(n.P, n.qmask, n.Pq, n.nTrain, c->st);
 }
 
+// the plan of one convolution of this context: bf16 matrix pipe where configured and covered, else fp32
+static ConvPlan plan_conv(const depgan_ctx* c, int KS, int Cin, int Cout) {
+  return c->cfg.bf16_mfma ? dg_plan_conv_bf16(KS, Cin, Cout) : dg_plan_conv(KS, Cin, Cout);
+}
+
 // ---------------------------------------------------------------------------
 // profiling helpers
 // ---------------------------------------------------------------------------
@@ -104,7 +109,8 @@ int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
   const int ng = a.groups > 1 ? a.groups : 1;
   const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cin * a.Cout * KS * KS * ng;
   char lb[56];
-  snprintf(lb, sizeof(lb), "conv k%d b%d %dx%d %d->%d%s", KS, a.B, a.H, a.W, a.Cin, a.Cout, ng > 1 ? " x4" : "");
+  snprintf(lb, sizeof(lb), "conv%s k%d b%d %dx%d %d->%d%s", pl.bf16 ? "(bf16)" : "", KS, a.B, a.H, a.W, a.Cin, a.Cout,
+           ng > 1 ? " x4" : "");
   // algorithmic bytes: every operand the epilogue names read once, every result written once, weights once
   const double px = 4.0 * a.B * a.H * a.W;
   const double by = px * a.Cin + ng * (px * a.Cout * (1 + (a.ep.res.p ? 1 : 0) + (a.ep.mask.p ? 1 : 0) +
@@ -387,8 +393,8 @@ static int build_generator(depgan_ctx* c) {
       L.s = take(L.Cout); L.t = take(L.Cout); L.rstd = take(L.Cout);
     }
     if (e.kind == G_CONV) {
-      L.pf = dg_plan_conv(3, L.Cin, L.Cout);
-      L.pb = dg_plan_conv(3, L.Cout, L.Cin);
+      L.pf = plan_conv(c, 3, L.Cin, L.Cout);
+      L.pb = plan_conv(c, 3, L.Cout, L.Cin);
       if (L.pf.variant >= 0) DGCHECK(dmalloc(c, &L.wpf[0], L.pf.packedFloats));
       if (i > 0 && L.pb.variant >= 0) DGCHECK(dmalloc(c, &L.wpb[0], L.pb.packedFloats));
       const bool skip = (i + 1 < kNTrunk && kTrunk[i + 1].kind == G_POOL);
@@ -409,8 +415,8 @@ static int build_generator(depgan_ctx* c) {
       }
       cur = L.out;
     } else if (e.kind == G_FILM) {
-      L.pf = dg_plan_conv(3, L.Cin, L.Cout);
-      L.pb = dg_plan_conv(3, L.Cout, L.Cin);
+      L.pf = plan_conv(c, 3, L.Cin, L.Cout);
+      L.pb = plan_conv(c, 3, L.Cout, L.Cin);
       DGCHECK(dmalloc(c, &L.wpf[0], L.pf.packedFloats));
       DGCHECK(dmalloc(c, &L.wpb[0], L.pb.packedFloats));
       const std::string key = e.aux;
@@ -441,14 +447,14 @@ static int build_generator(depgan_ctx* c) {
       W /= 2;
       cur = L.out;
     } else if (e.kind == G_DECONV) {
-      L.pf = dg_plan_conv(1, L.Cin, L.Cout);
-      L.pb = dg_plan_conv(1, L.Cout, L.Cin);
+      L.pf = plan_conv(c, 1, L.Cin, L.Cout);
+      L.pb = plan_conv(c, 1, L.Cout, L.Cin);
       for (int t = 0; t < 4; ++t) {
         DGCHECK(dmalloc(c, &L.wpf[t], L.pf.packedFloats));
         DGCHECK(dmalloc(c, &L.wpb[t], L.pb.packedFloats));
       }
-      L.pbf = dg_plan_conv(1, 4 * L.Cout, L.Cin);
-      if (L.pb.variant >= 0 && L.pbf.variant == L.pb.variant && (L.Cout % L.pb.CK) == 0 &&
+      L.pbf = plan_conv(c, 1, 4 * L.Cout, L.Cin);
+      if (L.pb.variant >= 0 && L.pbf.variant == L.pb.variant && L.pbf.bf16 == L.pb.bf16 && (L.Cout % L.pb.CK) == 0 &&
           L.pbf.packedFloats == 4 * L.pb.packedFloats)
         DGCHECK(dmalloc(c, &L.wpb_all, L.pbf.packedFloats));
       Cat& ct = cats[e.aux];
@@ -499,8 +505,8 @@ static int build_critics(depgan_ctx* c) {
     L.pool = kDis[l].pool;
     L.H = H;
     L.W = W;
-    L.pf = dg_plan_conv(L.KS, L.Cin, L.Cout);
-    L.pb = dg_plan_conv(L.KS, L.Cout, L.Cin);
+    L.pf = plan_conv(c, L.KS, L.Cin, L.Cout);
+    L.pb = plan_conv(c, L.KS, L.Cout, L.Cin);
     DGCHECK(talloc(c, &c->d_act[l], c->NB3, H, W, L.Cout));
     DGCHECK(talloc(c, &c->d_dz[l], c->NB3, H, W, L.Cout));
     if (L.pool) {
@@ -619,8 +625,9 @@ int refresh_generator(depgan_ctx* c) {
           if (L.wpb_all) {
             // panel of channel tile nt, tap t -> [nt][t][chunk][n][k]: the K axis of the fused backward-data launch
             // is (tap, channel); the per-tap panels are written straight into that interleaved layout
-            const size_t blk = (size_t)L.pb.nCC * L.pb.NT * L.pb.CK;
-            DGCHECK(dg_pack_job(L.pb, src, L.Cin, L.Cout, 1, 1, 0, ks, L.wpb_all + t * blk, 4 * blk, &j));
+            const size_t blk = (size_t)L.pb.nCC * L.pb.NT * L.pb.CK;      // elements
+            float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(L.wpb_all) + t * blk * dg_plan_elem_bytes(L.pb));
+            DGCHECK(dg_pack_job(L.pb, src, L.Cin, L.Cout, 1, 1, 0, ks, dst, 4 * blk, &j));
           } else {
             DGCHECK(dg_pack_job(L.pb, src, L.Cin, L.Cout, 1, 1, 0, ks, L.wpb[t], 0, &j));
           }
@@ -1102,8 +1109,8 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
                  (int)sizeof(depgan_config));
     return DG_ERR_ARG;
   }
-  if (cfg->bf16_mfma && !cfg->bf16_weights) {
-    dg_set_error("depgan_create: bf16_mfma needs bf16_weights = 1");
+  if (cfg->bf16_mfma && (!cfg->bf16_weights || (cfg->nc_out != 0 && cfg->nc_out != 1))) {
+    dg_set_error("depgan_create: bf16_mfma needs bf16_weights = 1 and the DEP-GAN generator (nc_out = 1)");
     return DG_ERR_ARG;
   }
   if (cfg->batch < 1 || cfg->height % 16 || cfg->width % 16 || cfg->height < 16 || cfg->width < 16 || cfg->nicg < 1 ||
@@ -1438,7 +1445,8 @@ static int op_conv(const float* in, const float* w_hwio, const float* bias, floa
   a.B = B; a.H = H; a.W = W; a.Cin = ci; a.Cout = co;
   a.ep.bias = bias;
   a.ep.relu = relu;
-  ConvPlan pl = dg_plan_conv(KS, ci, co);
+  ConvPlan pl = (path == 3) ? dg_plan_conv_bf16(KS, ci, co) : dg_plan_conv(KS, ci, co);
+  if (path == 3 && !pl.bf16) { dg_set_error("op_conv: the bf16 MFMA kernel does not cover this shape"); return DG_ERR_UNSUPPORTED; }
   if (path == 1 && pl.variant < 0) { dg_set_error("op_conv: MFMA path not available for this shape"); return DG_ERR_UNSUPPORTED; }
   if (path != 2 && pl.variant >= 0) {
     float* wp = nullptr;

@@ -191,7 +191,7 @@ int depgan_data_prep_subject(const float* p1_dev, const float* f1_dev, const flo
                              int nicg, float* x_out_dev, float* y2_out_dev, float* scratch_dev, void* stream);
 
 /* ---- single operators (unit-test surface; device pointers) ---- */
-/* path: 0 auto, 1 MFMA implicit GEMM, 2 direct */
+/* path: 0 auto, 1 fp32 MFMA implicit GEMM, 2 direct, 3 bf16 MFMA implicit GEMM (both operands rounded to bf16, RNE) */
 int depgan_op_conv2d(const float* in, const float* w_hwio, const float* bias, float* out, int B, int H, int W,
                      int Cin, int Cout, int KS, int relu, int path, void* hip_stream);
 int depgan_op_conv2d_bwd_data(const float* dy, const float* w_hwio, float* dx, int B, int H, int W, int Cin,

@@ -195,9 +195,38 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1)
 
 
+# BASELINE config 4 on the bf16 matrix pipe: "the same graph with bf16-rounded operands".  When the switch is
+# on, the activation operand of every convolution that the HIP build runs on v_mfma_f32_32x32x16_bf16 (Cout a multiple
+# of 32, Cin >= 8 and a multiple of 4 -- csrc/igemm_bf16.hip, dg_plan_conv_bf16) is rounded to bf16 (RNE) first; the
+# weights are rounded by round_kernels_bf16.  Straight-through in the backward pass (the HIP build additionally rounds
+# the gradient operand of its backward-data convolutions: the gradient tolerance of config 4 covers that).
+_ACT_BF16 = False
+
+
+class bf16_activations:
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        global _ACT_BF16
+        self.prev, _ACT_BF16 = _ACT_BF16, self.on
+
+    def __exit__(self, *exc):
+        global _ACT_BF16
+        _ACT_BF16 = self.prev
+
+
+def _act_operand(x, cin, cout):
+    if not _ACT_BF16 or cout % 32 != 0 or cin < 8 or cin % 4 != 0:
+        return x
+    q = x.detach().to(torch.float32).to(torch.bfloat16).to(x.dtype)
+    return x + (q - x.detach())
+
+
 def _conv_same(x, w_hwio, b):
     """keras Conv2D(padding='same', stride 1), NCHW in/out, HWIO kernel."""
     k = w_hwio.shape[0]
+    x = _act_operand(x, w_hwio.shape[2], w_hwio.shape[3])
     return F.conv2d(x, w_hwio.permute(3, 2, 0, 1), b, padding=k // 2)
 
 
@@ -249,6 +278,7 @@ def g_forward_t(T, x, z, nicg=1, fm=32, nc_out=1, head="tanh", taps=None):
             a = F.max_pool2d(a, 2)
         elif kind == "deconv":
             w = T["deconv2d_" + name + "/kernel"]            # (kh,kw,Cout,Cin)
+            a = _act_operand(a, w.shape[3], w.shape[2])
             a = F.conv_transpose2d(a, w.permute(3, 2, 0, 1), T["deconv2d_" + name + "/bias"], stride=2)
             a = torch.relu(_bn_infer(a, T, "bn_" + name))
             a = torch.cat([a, skips[ent[4]]], dim=1)         # GT:450 order [deconv, skip]
@@ -421,8 +451,9 @@ class OracleTrainers:
     weights_dtype="bfloat16": gradients are taken at the bf16-rounded kernels and applied to the fp32 masters."""
 
     def __init__(self, PG, PDy2, PDdem, lrD=1e-4, lrG=1e-4, delta=10.0, thr=0.5, nicg=1,
-                 dtype=torch.float32, weights_dtype="float32"):
+                 dtype=torch.float32, weights_dtype="float32", activations_dtype="float32"):
         self._PG, self._PDy2, self._PDdem = PG, PDy2, PDdem
+        self._act = activations_dtype == "bfloat16"
         self._q = round_kernels_bf16 if weights_dtype == "bfloat16" else (lambda P: P)
         self.delta, self.thr, self.nicg, self.dtype = delta, thr, nicg, dtype
         self.optD_y2 = KerasAdam(trainable_names(PDy2), lrD, 0.0, 0.9)   # GT:549
@@ -430,22 +461,38 @@ class OracleTrainers:
         self.optG = KerasAdam(trainable_names(PG), lrG, 0.0, 0.9)        # GT:594
 
     def netD_y2_train(self, inputs):
+        with bf16_activations(self._act):
+            return self._netD_y2_train(inputs)
+
+    def _netD_y2_train(self, inputs):
         y2, x, z, ep = inputs
         outs, grads, _ = critic_grads(self.PDy2, self.PG, y2, x, z, ep, "y2", self.delta, self.nicg, self.dtype)
         self.optD_y2.apply(self._PDy2, grads)
         return outs
 
     def netD_dem_train(self, inputs):
+        with bf16_activations(self._act):
+            return self._netD_dem_train(inputs)
+
+    def _netD_dem_train(self, inputs):
         y2, x, z, ep = inputs
         outs, grads, _ = critic_grads(self.PDdem, self.PG, y2, x, z, ep, "dem", self.delta, self.nicg, self.dtype)
         self.optD_dem.apply(self._PDdem, grads)
         return outs
 
     def netG_no_update(self, inputs):
+        with bf16_activations(self._act):
+            return self._netG_no_update(inputs)
+
+    def _netG_no_update(self, inputs):
         x, y2, z = inputs
         return g_eval(self.PG, self.PDy2, self.PDdem, x, y2, z, self.thr, self.nicg, self.dtype)
 
     def netG_train(self, inputs):
+        with bf16_activations(self._act):
+            return self._netG_train(inputs)
+
+    def _netG_train(self, inputs):
         x, y2, z = inputs
         outs, grads = g_grads(self.PG, self.PDy2, self.PDdem, x, y2, z, self.thr, self.nicg, self.dtype)
         self.optG.apply(self._PG, grads)

@@ -64,6 +64,50 @@ def test_conv_forward_and_backward_data(lib, case):
     assert rel(dx.cpu().numpy(), gx.permute(0, 2, 3, 1).numpy()) < TOL
 
 
+def _bf16(a):
+    """float32 -> nearest bf16 (ties to even) -> float32, what v_cvt_pk_bf16_f32 does to both MFMA operands."""
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+BF16_CASES = [  # B,H,W,Cin,Cout,k: every variant of igemm_bf16.hip, ragged tiles, Cin below / not a multiple of a chunk
+    (2, 32, 32, 32, 32, 3), (2, 48, 40, 32, 64, 3), (1, 32, 32, 224, 96, 3), (2, 21, 19, 64, 160, 3),
+    (2, 32, 32, 16, 32, 5), (2, 32, 32, 32, 32, 5), (2, 17, 33, 32, 64, 5), (2, 32, 32, 128, 128, 1),
+    (2, 32, 32, 48, 96, 3), (1, 16, 16, 256, 256, 3), (2, 30, 18, 8, 32, 3), (2, 32, 32, 384, 96, 1),
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_bf16_mfma_conv_forward_and_backward_data(lib, case):
+    """BASELINE configs[3] on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16): both operands rounded to bf16 (RNE), fp32
+    accumulation, fp32 epilogue.  The reference multiplies the SAME rounded operands in float64, so what is left is
+    the summation order: the fp32 tolerance holds."""
+    from dep_gan_im_amd import _lib
+    B, H, W, ci, co, k = case
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(ci * 1000 + co + k)
+    x = rng.standard_normal((B, H, W, ci)).astype(np.float32)
+    w = (rng.standard_normal((k, k, ci, co)) / np.sqrt(k * k * ci)).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, co)).astype(np.float32)
+    xd, wd, bd, dyd = [torch.from_numpy(a).to(dev) for a in (x, w, b, dy)]
+    out = torch.full((B, H, W, co), float("nan"), device=dev)
+    _lib.check(lib.depgan_op_conv2d(P(xd), P(wd), P(bd), P(out), B, H, W, ci, co, k, 1, 3, None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert rel(got, _ref_conv(_bf16(x), _bf16(w), b, True)) < TOL
+    assert rel(got, _ref_conv(x, w, b, True)) > 5 * TOL           # the rounding is there (and we follow it)
+    if ci % 32 == 0 and ci >= 8 and co >= 8 and co % 4 == 0:       # backward-data = a convolution with Cout_bwd = Cin
+        dx = torch.full((B, H, W, ci), float("nan"), device=dev)
+        _lib.check(lib.depgan_op_conv2d_bwd_data(P(dyd), P(wd), P(dx), B, H, W, ci, co, k, 3, None))
+        torch.cuda.synchronize()
+        xt = torch.from_numpy(x).permute(0, 3, 1, 2).double().requires_grad_(True)
+        y = F.conv2d(xt, torch.from_numpy(_bf16(w)).permute(3, 2, 0, 1).double(), padding=k // 2)
+        (gx,) = torch.autograd.grad(y, xt, torch.from_numpy(_bf16(dy)).permute(0, 3, 1, 2).double())
+        assert rel(dx.cpu().numpy(), gx.permute(0, 2, 3, 1).numpy()) < TOL
+    # shapes the bf16 kernel does not cover are refused on this path (the model falls back to the fp32 pipe for them)
+    assert lib.depgan_op_conv2d(P(xd), P(wd), P(bd), P(out), B, H, W, ci, 16, k, 1, 3, None) != 0   # refused before any launch
+
+
 WGRAD_CASES = [(2, 32, 32, 32, 32, 3), (3, 48, 40, 64, 64, 3), (2, 23, 17, 96, 32, 3), (2, 16, 16, 256, 256, 3),
                (2, 32, 32, 16, 16, 5), (2, 32, 32, 16, 32, 5), (2, 32, 24, 32, 32, 5), (2, 32, 32, 128, 128, 1),
                (2, 32, 32, 1, 32, 3), (2, 32, 32, 2, 32, 3), (2, 32, 32, 1, 16, 5), (4, 64, 64, 32, 64, 3),
