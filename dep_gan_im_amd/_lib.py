@@ -20,6 +20,7 @@ EXPORTS = [
     "depgan_uresnet_eval", "depgan_profile_read_bytes", "depgan_g_eval_multi", "depgan_eval_accumulate", "depgan_eval_counts",
     "depgan_data_prep_scratch_floats", "depgan_data_prep_subject", "depgan_abi_version", "depgan_config_size",
     "depgan_set_allreduce", "depgan_get_adam_step", "depgan_set_adam_step", "depgan_gen_iteration", "depgan_eval_divide",
+    "depgan_source_hash",
 ]
 
 ABI_VERSION = 2          # DEPGAN_ABI_VERSION of the include/depgan.h this binding was written against
@@ -75,6 +76,13 @@ def load():
         raise DepganError("libdepgan.so at %s has ABI %d / depgan_config of %d bytes, this binding expects ABI %d / %d "
                           "bytes: rebuild with `python -m dep_gan_im_amd.build`"
                           % (LIB_PATH, lib.depgan_abi_version(), lib.depgan_config_size(), ABI_VERSION, C.sizeof(Config)))
+    lib.depgan_source_hash.restype = C.c_char_p
+    if os.path.isdir(os.path.join(HERE, "csrc")) and not os.environ.get("DEPGAN_LIB"):
+        from .build import source_hash
+        built, here = lib.depgan_source_hash().decode(), source_hash()
+        if built != here:
+            raise DepganError("libdepgan.so at %s was built from other sources (hash %s, the sources here hash to %s): "
+                              "rebuild with `python -m dep_gan_im_amd.build`" % (LIB_PATH, built, here))
     lib.depgan_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, C.c_int]
     lib.depgan_get_adam_step.argtypes = [vp, C.c_int]
     lib.depgan_get_adam_step.restype = C.c_long

@@ -26,6 +26,21 @@ def _hipcc():
     return "hipcc"
 
 
+def source_hash():
+    """sha256 over every source the library is built from (csrc/*.hip, *.h, *.inc and include/depgan.h), in name order.
+    It is compiled into the library (depgan_source_hash()), so a stale libdepgan.so -- e.g. one cross-compiled from
+    other sources and shipped next to these -- is detected at load time instead of silently running old kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc")))
+    files.append(os.path.join(HERE, "..", "include", "depgan.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:32]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -58,6 +73,16 @@ def _build_locked(force, verbose):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + headers):
             jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+    # the source hash lives in a translation unit of its own, rebuilt whenever it changes (i.e. whenever anything does)
+    digest = source_hash()
+    stamp_src = os.path.join(objdir, "srchash.cpp")
+    stamp_obj = os.path.join(objdir, "srchash.o")
+    text = 'extern "C" const char* depgan_source_hash(void) { return "%s"; }\n' % digest
+    if not os.path.exists(stamp_src) or open(stamp_src).read() != text:
+        with open(stamp_src, "w") as fh:
+            fh.write(text)
+    if force or _stale(stamp_obj, [stamp_src]):
+        jobs.append(["g++", "-O1", "-fPIC", "-c", stamp_src, "-o", stamp_obj])
 
     def run(cmd):
         # the output is written next to its final name and renamed, so a reader never sees a partial file
@@ -75,7 +100,7 @@ def _build_locked(force, verbose):
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES] + [stamp_obj]
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB])
     return LIB

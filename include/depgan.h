@@ -26,6 +26,9 @@ typedef struct depgan_ctx depgan_ctx;
 #define DEPGAN_ABI_VERSION 2
 int depgan_abi_version(void);
 size_t depgan_config_size(void);
+/* first 32 hex digits of the sha256 over the sources this binary was built from (dep_gan_im_amd/build.py::source_hash):
+ * the Python binding compares it with the sources lying next to it and refuses a stale library */
+const char* depgan_source_hash(void);
 
 typedef struct depgan_config {
   int struct_size;  /* = sizeof(depgan_config); checked by depgan_create                */

@@ -137,3 +137,18 @@ def test_create_rejects_a_config_of_another_size(lib):
     assert b"struct_size" in lib.depgan_last_error()
     cfg.struct_size = 0                      # a caller that never heard of the field
     assert lib.depgan_create(C.byref(cfg), C.byref(h)) != 0
+
+
+def test_library_carries_the_hash_of_the_sources_it_was_built_from(lib, tmp_path, monkeypatch):
+    """The GPU box loads the library that was cross-compiled here: the binding refuses one whose embedded source hash
+    is not the hash of the sources lying next to it."""
+    from dep_gan_im_amd import build
+    assert lib.depgan_source_hash().decode() == build.source_hash()
+    real = build.source_hash
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 32)
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.DepganError, match="other sources"):
+        _lib.load()
+    monkeypatch.setattr(build, "source_hash", real)
+    monkeypatch.setattr(_lib, "_lib", None)
+    assert _lib.load() is not None
