@@ -594,6 +594,7 @@ int refresh_generator_bn(depgan_ctx* c) {
     c->g_n_bn = (int)jobs.size();
     DGCHECK(upload_table(c, jobs, &c->g_bn_jobs));
   }
+  ProfScope ps(c, 2, 0.0, "bn affine refresh");
   return dg_bn_prepare_batch(c->g_bn_jobs, c->g_n_bn, eps, c->st);
 }
 
@@ -639,6 +640,7 @@ int refresh_generator(depgan_ctx* c) {
     c->g_pack_blocks = dg_pack_layout(jobs.data(), c->g_n_pack);
     DGCHECK(upload_table(c, jobs, &c->g_pack_jobs));
   }
+  ProfScope ps(c, 2, 0.0, "pack weights");
   return dg_pack_weights_batch(c->g_pack_jobs, c->g_n_pack, c->g_pack_blocks, c->st);
 }
 
@@ -663,6 +665,7 @@ static int refresh_critic(depgan_ctx* c, DNet& D) {
     D.pack_blocks = dg_pack_layout(jobs.data(), D.n_pack);
     DGCHECK(upload_table(c, jobs, &D.pack_jobs));
   }
+  ProfScope ps(c, 2, 0.0, "pack weights");
   return dg_pack_weights_batch(D.pack_jobs, D.n_pack, D.pack_blocks, c->st);
 }
 
@@ -671,7 +674,7 @@ static int refresh_critic(depgan_ctx* c, DNet& D) {
 // ---------------------------------------------------------------------------
 int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u) {
   {
-    ProfScope ps(c, 2, 0.0);
+    ProfScope ps(c, 2, 0.0, "noise mlp fwd");
     DGCHECK(dg_noise_fwd(c->np, z, c->na, n, c->st));
   }
   bool pooled_by_conv = false;
@@ -706,7 +709,7 @@ int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u
       DGCHECK(conv_launch(c, L.pf, a, 3));
     } else if (L.kind == G_POOL) {
       if (pooled_by_conv && L.skip_of == (int)i - 1) continue;
-      ProfScope ps(c, 2, 0.0);
+      ProfScope ps(c, 2, 0.0, "maxpool");
       DGCHECK(dg_maxpool(c->gl[L.skip_of].out, L.out, n, L.H / 2, L.W / 2, L.Cout, c->st));
     } else if (L.kind == G_DECONV) {
       // 2x2 / stride-2 transposed convolution = four 1x1 convolutions of the same input, tap (di, dj) writing the
@@ -726,7 +729,7 @@ int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u
       a.w = L.wpf[0];
       DGCHECK(conv_launch(c, L.pf, a, 1));
     } else if (L.kind == G_HEAD && c->cfg.nc_out == 1) {
-      ProfScope ps(c, 2, 0.0);
+      ProfScope ps(c, 2, 0.0, "head fwd");
       DGCHECK(dg_head_fwd(L.in.p, L.Wt, L.b, c->attr.p, (long)n * L.H * L.W, L.Cin, 1, c->st));
     }
   }
@@ -740,7 +743,7 @@ static int g_conv_bn_bwd(depgan_ctx* c, GLayer& L, size_t li, const float* x_use
   const ColSum cs = {n, L.s, L.db, L.dbeta};
   DGCHECK(wgrad_full(c, 3, xin, dy, n, L.H, L.W, L.Cin, L.Cout, L.s, L.dW, c->raw, 0, 0, &cs));
   {
-    ProfScope ps(c, 2, 0.0);
+    ProfScope ps(c, 2, 0.0, "bn gamma grad");
     DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 9 * L.Cin, L.Cout, 0, L.Cin, L.b, L.mean, L.rstd, L.dbeta, L.dgamma,
                              c->st));
   }
@@ -761,7 +764,7 @@ int g_backward(depgan_ctx* c, const float* x, const float* z, int n) {
   for (int i = (int)c->gl.size() - 1; i >= 0; --i) {
     GLayer& L = c->gl[i];
     if (L.kind == G_HEAD) {
-      ProfScope ps(c, 2, 0.0);
+      ProfScope ps(c, 2, 0.0, "head bwd");
       const long P = (long)n * L.H * L.W;
       // dW[c] = sum_p dpre[p] a[p][c] ; db = sum dpre
       DGCHECK(dg_colsum_rowmul(L.in, n, L.H, L.W, L.Cin, c->dpre, L.dW, c->scratch, c->st));
@@ -772,20 +775,20 @@ int g_backward(depgan_ctx* c, const float* x, const float* z, int n) {
     } else if (L.kind == G_FILM) {
       TView du = make_view(c->du_tmp.p, L.H, L.W, L.Cout);
       {
-        ProfScope ps(c, 2, 0.0);
+        ProfScope ps(c, 2, 0.0, "film bwd");
         DGCHECK(dg_film_bwd(L.dout.p, L.u.p, c->na.heads + L.col_mul, c->na.heads + L.col_add, 1024, du.p,
                             c->dheads + L.col_mul, c->dheads + L.col_add, n, (long)L.H * L.W, L.Cout, c->scratch,
                             c->st));
       }
       DGCHECK(g_conv_bn_bwd(c, L, (size_t)i, x, du, L.dout, n));
     } else if (L.kind == G_POOL) {
-      ProfScope ps(c, 2, 0.0);
+      ProfScope ps(c, 2, 0.0, "unpool+mask");
       DGCHECK(dg_unpool_mask(L.pool_dsrc, c->gl[L.skip_of].out, L.pool_skipgrad, L.pool_dst, n, L.H / 2, L.W / 2,
                              L.Cout, c->st));
     } else if (L.kind == G_DECONV) {
       const int Ho = 2 * L.H, Wo = 2 * L.W;
       {
-        ProfScope ps(c, 2, 0.0);
+        ProfScope ps(c, 2, 0.0, "colsum");
         DGCHECK(dg_colsum(L.dout, n, Ho, Wo, L.Cout, L.s, L.db, L.dbeta, 0, c->scratch, c->st));
       }
       for (int t = 0; t < 4; ++t) {
@@ -794,14 +797,14 @@ int g_backward(depgan_ctx* c, const float* x, const float* z, int n) {
                            c->raw + o, 0, 1));
       }
       {
-        ProfScope ps(c, 2, 0.0);
+        ProfScope ps(c, 2, 0.0, "bn gamma grad");
         DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 4 * L.Cin, L.Cout, 1, L.Cin, L.b, L.mean, L.rstd, L.dbeta, L.dgamma,
                                  c->st));
       }
       DGCHECK(deconv_bwd_data(c, L, L.dout, n));
     }
   }
-  ProfScope ps(c, 2, 0.0);
+  ProfScope ps(c, 2, 0.0, "noise mlp bwd");
   return dg_noise_bwd(c->np, c->ng, z, c->na, c->dheads, c->scratch, n, c->st);
 }
 
@@ -834,13 +837,13 @@ static int d_forward(depgan_ctx* c, DNet& D, const float* img, long s0, int N) {
     }
     DGCHECK(conv_launch(c, L.pf, a, L.KS));
     if (L.pool && !a.ep.pool.p) {
-      ProfScope ps(c, 2, 0.0);
+      ProfScope ps(c, 2, 0.0, "maxpool");
       DGCHECK(dg_maxpool(a.out, view_offset(c->d_pool[l].view(), s0), N, L.H / 2, L.W / 2, L.Cout, c->st));
     }
   }
   const DLayer& T = c->dl[10];
   const int HW = T.H * T.W;
-  ProfScope ps(c, 2, 0.0);
+  ProfScope ps(c, 2, 0.0, "critic tail fwd");
   return dg_critic_tail_fwd(c->d_act[10].p + s0 * c->d_act[10].per_sample(), D.w9, D.b9, D.wd, D.bd,
                             c->d_t9 + s0 * HW, c->d_out + s0, N, HW, 256, c->st);
 }
@@ -852,7 +855,7 @@ static int d_backward_chain(depgan_ctx* c, DNet& D, long s0, int N, const float*
   const DLayer& T = c->dl[10];
   const int HW = T.H * T.W;
   {
-    ProfScope ps(c, 2, 0.0);
+    ProfScope ps(c, 2, 0.0, "critic tail bwd");
     DGCHECK(dg_critic_tail_bwd(c->d_act[10].p + s0 * c->d_act[10].per_sample(), D.w9, D.wd, coefs, per,
                                c->d_dz[10].p + s0 * c->d_dz[10].per_sample(), N, HW, 256, c->st));
   }
@@ -873,7 +876,7 @@ static int d_backward_chain(depgan_ctx* c, DNet& D, long s0, int N, const float*
     }
     DGCHECK(conv_launch(c, L.pb, a, L.KS));
     if (Pv.pool) {
-      ProfScope ps(c, 2, 0.0);
+      ProfScope ps(c, 2, 0.0, "unpool+mask");
       DGCHECK(dg_unpool_mask(a.out, view_offset(c->d_act[l - 1].view(), s0), null_view(),
                              view_offset(c->d_dz[l - 1].view(), s0), N, Pv.H / 2, Pv.W / 2, Pv.Cout, c->st));
     }
@@ -889,7 +892,7 @@ static int d_backward_chain(depgan_ctx* c, DNet& D, long s0, int N, const float*
     // transposed + flipped access of the HWIO kernel (Cin_f = 1): w(tap', k = co_f, n = 0)
     a.w = D.W[0];
     a.wsT = (long)L.Cin * L.Cout; a.wsI = 1; a.wsO = L.Cout; a.flip = 1;
-    ConvPlan none;
+    ConvPlan none = {};
     none.variant = -1;
     DGCHECK(conv_launch(c, none, a, L.KS));
   }
@@ -901,7 +904,7 @@ int net_adam(depgan_ctx* c, Net& n, float gscale) {
   const double b1 = c->cfg.beta1, b2 = c->cfg.beta2;
   const double t = (double)n.adam_t;
   const double lr_t = n.lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
-  ProfScope ps(c, 2, 0.0);
+  ProfScope ps(c, 2, 0.0, "adam");
   return dg_adam(n.P, n.G, n.M, n.V, n.nTrain, (float)lr_t, (float)b1, (float)b2, c->cfg.adam_eps, gscale, c->st);
 }
 
@@ -917,7 +920,7 @@ static int critic_enqueue(depgan_ctx* c, int which, const float* y2, const float
   const long HW0 = (long)H0 * W0;
   DGCHECK(g_forward(c, x, z, B, false));
   {
-    ProfScope ps(c, 2, 0.0);
+    ProfScope ps(c, 2, 0.0, "critic inputs");
     DGCHECK(dg_critic_inputs(y2, x, c->cfg.nicg, c->attr.p, ep, c->d_in, B, HW0, which, c->st));
   }
   DGCHECK(d_forward(c, D, c->d_in, 0, 3 * B));
@@ -925,7 +928,7 @@ static int critic_enqueue(depgan_ctx* c, int which, const float* y2, const float
   DGCHECK(d_backward_chain(c, D, 0, 3 * B, c->coefs, B, 2 * B, B, c->g0));
   float* u0 = c->d_in + 2 * B * HW0;
   {
-    ProfScope ps(c, 2, 0.0);
+    ProfScope ps(c, 2, 0.0, "gp norms+u0");
     DGCHECK(dg_gp_u0(c->g0, u0, c->norms, nullptr, c->cfg.delta, B, HW0, c->scratch, c->st));
   }
   // u-forward through the masks of the mixed pass, overwriting the mixed slots
@@ -950,7 +953,7 @@ static int critic_enqueue(depgan_ctx* c, int which, const float* y2, const float
     }
     DGCHECK(conv_launch(c, L.pf, a, L.KS));
     if (L.pool) {
-      ProfScope ps(c, 2, 0.0);
+      ProfScope ps(c, 2, 0.0, "gather pool");
       DGCHECK(dg_gather_pool(a.out, act, view_offset(c->d_pool[l].view(), 2 * B), B, L.H / 2, L.W / 2, L.Cout,
                              c->st));
     }
@@ -965,7 +968,7 @@ static int critic_enqueue(depgan_ctx* c, int which, const float* y2, const float
                        0, &cs));
   }
   {
-    ProfScope ps(c, 2, 0.0);
+    ProfScope ps(c, 2, 0.0, "critic tail wgrad+stats");
     const DLayer& T = c->dl[10];
     const int HW = T.H * T.W;
     DGCHECK(dg_critic_tail_wgrad(c->d_act[10].p, D.w9, D.b9, D.wd, c->coefs, B, 1, 0, D.dw9, D.db9, D.dwd, D.dbd,
@@ -986,13 +989,13 @@ static int g_eval_enqueue(depgan_ctx* c, const float* x, const float* y2, const 
   const long HW0 = (long)H0 * W0, P = (long)B * HW0;
   DGCHECK(g_forward(c, x, z, B, train));
   {
-    ProfScope ps(c, 2, 0.0);
+    ProfScope ps(c, 2, 0.0, "fake_y2");
     DGCHECK(dg_add_ch0(x, c->cfg.nicg, c->attr.p, c->fake_y2, P, c->st));
   }
   DGCHECK(d_forward(c, c->d[0], c->fake_y2, 0, B));
   DGCHECK(d_forward(c, c->d[1], c->attr.p, B, B));
   {
-    ProfScope ps(c, 2, 0.0);
+    ProfScope ps(c, 2, 0.0, "g loss sums");
     DGCHECK(dg_sum_groups_consts(c->d_out, stats_dev, 2, B, 6, (float)B, (float)P, c->st));
     DGCHECK(dg_gloss_sums(x, c->cfg.nicg, y2, c->attr.p, c->cfg.im_thresh, stats_dev + 2, P, c->scratch, c->st));
   }
@@ -1001,7 +1004,7 @@ static int g_eval_enqueue(depgan_ctx* c, const float* x, const float* y2, const 
     DGCHECK(d_backward_chain(c, c->d[0], 0, B, c->coefs + 2, B, 0, B, c->g0));
     DGCHECK(d_backward_chain(c, c->d[1], B, B, c->coefs + 2, B, 0, B, c->g0 + P));
     {
-      ProfScope ps(c, 2, 0.0);
+      ProfScope ps(c, 2, 0.0, "g dpre");
       DGCHECK(dg_g_dpre(x, c->cfg.nicg, y2, c->attr.p, c->g0, c->g0 + P, c->dpre, B, P, c->st));
     }
     DGCHECK(g_backward(c, x, z, B));

@@ -227,7 +227,7 @@ static int u_head_logits(depgan_ctx* c, int n) {
   a.ep.bias = L.b;
   a.w = L.Wt;
   a.wsT = (long)L.Cin * 4; a.wsI = 4; a.wsO = 1;
-  ConvPlan none;
+  ConvPlan none = {};
   memset(&none, 0, sizeof(none));
   none.variant = -1;
   return conv_launch(c, none, a, 1);
@@ -281,7 +281,7 @@ static int u_backward(depgan_ctx* c, const float* x, const float* z, int n) {
       a.w = L.Wt;                               // W[ci][co] read as (k = co, n = ci)
       a.wsT = (long)L.Cin * 4; a.wsI = 1; a.wsO = 4;
       a.ep.mask = L.in_mask;
-      ConvPlan none;
+      ConvPlan none = {};
       memset(&none, 0, sizeof(none));
       none.variant = -1;
       DGCHECK(conv_launch(c, none, a, 1));
