@@ -396,7 +396,7 @@ def main():
     # ---- extra, never the headline: BASELINE configs[3] on the bf16 matrix pipe (256x256x2, bf16 weights AND
     # activations into v_mfma_f32_32x32x16_bf16, fp32 accumulate / masters / Adam) -- its own engine, its own roofline
     config4 = None
-    if rank == 0 and not os.environ.get("DEPGAN_BENCH_SKIP_CONFIG4"):
+    if world == 1 and rank == 0 and not os.environ.get("DEPGAN_BENCH_SKIP_CONFIG4"):
         config4 = bench_config4(dg, torch, dev, B)
     traffic, traffic_src = pmc_traffic(B)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",

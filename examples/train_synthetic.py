@@ -6,6 +6,11 @@ INTEGRATION.md shows: build the three models, build the four closures, then per 
 iterations, best-of-10 noise, one generator update), log, validate with predict, save the generator.
 
     python examples/train_synthetic.py --epochs 1 --slices 64 --batch 16
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 examples/train_synthetic.py   # data parallel
+
+The training set is moved to HBM once (a 288-GB device holds any realistic set of 256x256 slices), every generator
+iteration is one library call with one host synchronisation (depgan_gen_iteration), the full training state is
+checkpointed each epoch and --resume continues bit-identically.
 """
 import argparse
 import os
@@ -43,25 +48,45 @@ def main():
     ap.add_argument("--batch", type=int, default=16)       # batchSize, GT:32
     ap.add_argument("--size", type=int, default=256)       # imageSize
     ap.add_argument("--out", default="netG_synthetic.npz")
+    ap.add_argument("--state", default="train_state.npz", help="full training state (3 networks, Adam, counters)")
+    ap.add_argument("--resume", action="store_true")
     args = ap.parse_args()
 
+    import torch
     import dep_gan_im_amd as dg
     from dep_gan_im_amd.schedule import ScheduleState, train_epoch
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dp = None
+    if world > 1:                                     # one process per GPU; batchSize is the per-GPU batch
+        import torch.distributed as dist
+        from dep_gan_im_amd.dist import DataParallel
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        dp = DataParallel()
 
     imageSize, noiseSize, first_fm_G, nicg = args.size, 32, 32, 1
     netD_y2 = dg.Dis_C2D_FCN1((imageSize, imageSize, 1), seed=1)              # GT:513
     netD_dem = dg.Dis_C2D_FCN1((imageSize, imageSize, 1), seed=2)             # GT:516
     netG = dg.Gen_UNet2D((imageSize, imageSize, nicg), (noiseSize, 1), first_fm_G, 1, seed=3)   # GT:520
-    t = dg.build_trainers(netG, netD_y2, netD_dem, batchSize=args.batch, delta=10.0, lrD=1e-4, lrG=1e-4, IM_TRSH=0.178)
+    t = dg.build_trainers(netG, netD_y2, netD_dem, batchSize=args.batch, delta=10.0, lrD=1e-4, lrG=1e-4, IM_TRSH=0.178,
+                          dist=dp)
 
     train_1tp, train_2tp = synthetic_slices(args.slices, imageSize, 0)
+    train_1tp, train_2tp = torch.from_numpy(train_1tp).cuda(), torch.from_numpy(train_2tp).cuda()   # resident in HBM
     val_1tp, val_2tp = synthetic_slices(max(args.batch // 2, 2), imageSize, 1)
     fixed_noise = np.random.normal(size=(len(val_1tp), noiseSize, 1)).astype("float32")           # GT:772
 
     state = ScheduleState()
     state.gen_iterations = 26          # skip the 100-iteration critic warm-up of the first 25 iterations (GT:795)
+    if args.resume and os.path.exists(args.state):
+        t.load_state(args.state, state)
+        print("resumed at generator iteration", state.gen_iterations)
+    rng = np.random.RandomState(1234 + state.gen_iterations)      # identical on every rank: draws are for the GLOBAL batch
 
     def log(r):
+        if rank != 0:
+            return
         print("[%d] D_y2 %.4f (real %.4f fake %.4f)  D_dem %.4f  G %.4f (CY2 %.4f DEM %.4f L1 %.4f VOL %.4f DSC %.4f)  "
               "best noise %d" % (r["gen_iterations"], r["errD"], r["errD_real"], r["errD_fake"], r["errD_dem"], r["errG"],
                                  r["errG_CY2"], r["errG_DEM"], r["errG_MSE"], r["errG_VOL"], r["errG_WMH"], r["best_noise"]),
@@ -69,14 +94,20 @@ def main():
 
     for epoch in range(args.epochs):
         t0 = time.time()
-        train_epoch(t, train_1tp, train_2tp, batchSize=args.batch, Diters=5, state=state, on_gen_iteration=log)
+        train_epoch(t, train_1tp, train_2tp, batchSize=args.batch, Diters=5, state=state, on_gen_iteration=log, rng=rng,
+                    rank=rank, world=world)
         fake_dem = netG.predict([val_1tp, fixed_noise])                                            # GT:846-859
         val_real = float(netD_y2.predict(val_2tp).mean())
         val_fake = float(netD_y2.predict(val_1tp[..., 0:1] + fake_dem).mean())
         print("epoch %d: %.1f s, %d generator iterations so far; validation D_y2(real) %.4f D_y2(fake) %.4f"
               % (epoch + 1, time.time() - t0, state.gen_iterations, val_real, val_fake), flush=True)
-        netG.save(args.out)                                                                        # GT:892
-    print("saved", args.out)
+        if rank == 0:
+            netG.save(args.out)                                                                    # GT:892
+            t.save_state(args.state, state)
+    if rank == 0:
+        print("saved", args.out, "and", args.state)
+    if dp is not None:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
