@@ -8,6 +8,8 @@ from dep_gan_im_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
 def P(t): return C.c_void_p(t.data_ptr())
 shapes = [(32,256,256,32,32,3), (32,128,128,64,64,3), (32,256,256,96,32,3), (96,256,256,16,16,5)]
+if os.environ.get("AB_SHAPES"):     # e.g. AB_SHAPES="32,128,128,64,64,3;96,16,16,256,256,3"
+    shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["AB_SHAPES"].split(";")]
 variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
 for (B,H,W,ci,co,k) in shapes:
     x = torch.randn(B,H,W,ci, device=dev); w = torch.randn(k,k,ci,co, device=dev)*0.05; out = torch.empty(B,H,W,co, device=dev)
