@@ -166,6 +166,39 @@ def bench_config4(dg, torch, dev, B, steps=5):
                                  "class sits on the HBM side of the roofline" % (tf, tf / 2500.0)}}
 
 
+def bench_config5(dg, torch, dev, B, steps=5):
+    """One Model.train_on_batch of DEP-UResNet (UT:602-606): phase-1 BatchNorm, Dropout, softmax + categorical CE, Adam."""
+    rng = np.random.default_rng(5)
+    xs, _, z, _ = synth(3000, B)
+    xs = ((xs - xs.mean()) / xs.std()).astype(np.float32)                     # z-scored FLAIR stand-in (UT:511)
+    lab = np.eye(4, dtype=np.float32)[rng.integers(0, 4, (B, 256, 256))]      # one-hot (B,256,256,4) (UT:565-568)
+    x, z, lab = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (xs, z, lab)]
+    eng = dg.Engine(B, 256, 256, 1, lrG=1e-4, beta1=0.9, beta2=0.999, nc_out=4, device=dev)
+    for i in range(2):
+        eng.uresnet(x, z, lab, "step", drop_seed=i + 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.uresnet(x, z, lab, "step", drop_seed=10 + i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    eng.profile(True)
+    eng.profile_reset()
+    eng.uresnet(x, z, lab, "step", drop_seed=99)
+    parts = [eng.profile_read(k) for k in (0, 1, 2)]
+    eng.profile(False)
+    eng.profile_reset()
+    eng.close()
+    tf = 70.6e9 * B / (ms * 1e-3) / 1e12
+    return {"workload": "BASELINE configs[4]: DEP-UResNet train_on_batch (batch-statistics BatchNorm, Dropout(0.25), softmax + "
+                        "categorical cross-entropy, Adam(0.9, 0.999)), batch %d, 256x256x1, fp32" % B,
+            "ms_per_step": round(ms, 3), "slices_per_s": round(B / (ms * 1e-3), 1),
+            "achieved_tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_F32_MFMA, 4),
+            "gflop_per_slice": 70.6,
+            "ms_per_step_by_class": {"conv": round(parts[0][0], 3), "wgrad": round(parts[1][0], 3),
+                                     "other (batch statistics, affine / dropout passes, noise MLP)": round(parts[2][0], 3)}}
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with no launcher around it: start N ranks as a child torch.distributed.run (this
     process has not touched HIP and never will), relay rank 0's JSON line, exit with the child's status."""
@@ -398,6 +431,10 @@ def main():
     config4 = None
     if world == 1 and rank == 0 and not os.environ.get("DEPGAN_BENCH_SKIP_CONFIG4"):
         config4 = bench_config4(dg, torch, dev, B)
+    # ---- extra: BASELINE configs[4], the DEP-UResNet supervised step (learning phase 1, softmax / CE head) ----
+    config5 = None
+    if world == 1 and rank == 0 and not os.environ.get("DEPGAN_BENCH_SKIP_CONFIG5"):
+        config5 = bench_config5(dg, torch, dev, B)
     traffic, traffic_src = pmc_traffic(B)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": traffic,
@@ -436,6 +473,8 @@ def main():
             line["scaling_efficiency"] = round(value / (world * args.n1_value), 4)
         if config4 is not None:
             line["config4"] = config4
+        if config5 is not None:
+            line["config5"] = config5
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
