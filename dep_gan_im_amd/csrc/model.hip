@@ -1344,6 +1344,10 @@ int depgan_gen_iteration(depgan_ctx* c, const float* x_y2, const float* y2_y2, c
                  DEPGAN_MAX_CRITIC_STEPS, DEPGAN_MAX_MULTI);
     return DG_ERR_ARG;
   }
+  if ((n_y2 > 0 && (!x_y2 || !y2_y2 || !z_y2 || !ep_y2)) || (n_dem > 0 && (!x_dem || !y2_dem || !z_dem || !ep_dem))) {
+    dg_set_error("gen_iteration: a critic loop with n > 0 needs all four of its inputs");
+    return DG_ERR_ARG;
+  }
   const int B = c->cfg.batch;
   const long xs = batch_stride * c->cfg.height * c->cfg.width * c->cfg.nicg;
   const long ys = batch_stride * c->cfg.height * c->cfg.width;

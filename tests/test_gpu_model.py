@@ -225,6 +225,14 @@ def test_rccl_path_world1_matches_single_process(lib):
             tr = dg.build_trainers(*nets, batchSize=B, dist=DataParallel() if use_dist else None)
             o = tr.netD_y2_train([y2, x, z, ep]) + tr.netD_dem_train([y2, x, z, ep]) + tr.netG_no_update([x, y2, z]) \
                 + tr.netG_train([x, y2, z])
+            # ... and the one-call generator iteration, whose 4 collectives (2 critic updates, the k x 8 loss pieces of
+            # the noise search, the generator update) are enqueued from inside the library
+            zs = np.stack([z, z[::-1].copy(), 0.5 * z])
+            cy, cd, ev, g6, best = tr.gen_iteration((x, y2, z[None], ep[None], 1), (x, y2, z[None], ep[None], 1),
+                                                    (x, y2, zs))
+            o = o + cy[0] + cd[0] + [v for e in ev for v in e] + g6 + [float(best)]
+            if use_dist:
+                assert tr.dist.calls == 4 + 1 + 4           # closures: 3 updates + 1 evaluation; then the iteration's 4
             outs.append(o)
             weights.append([n.get_weights_dict() for n in nets])
         np.testing.assert_allclose(outs[0], outs[1], rtol=2e-6, atol=1e-7)
