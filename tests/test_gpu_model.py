@@ -232,7 +232,7 @@ def test_rccl_path_world1_matches_single_process(lib):
                                                     (x, y2, zs))
             o = o + cy[0] + cd[0] + [v for e in ev for v in e] + g6 + [float(best)]
             if use_dist:
-                assert tr.dist.calls == 4 + 1 + 4           # closures: 3 updates + 1 evaluation; then the iteration's 4
+                assert tr.dist.calls == 4 + 4               # closures: 3 updates + 1 evaluation; then the iteration's 4
             outs.append(o)
             weights.append([n.get_weights_dict() for n in nets])
         np.testing.assert_allclose(outs[0], outs[1], rtol=2e-6, atol=1e-7)
