@@ -166,6 +166,57 @@ def bench_config4(dg, torch, dev, B, steps=5):
                                  "class sits on the HBM side of the roofline" % (tf, tf / 2500.0)}}
 
 
+def bench_split(dg, torch, dev, B, x, y2, z, ep, steps=5):
+    """The headline workload (canonical step, 256x256x1, fp32 data and weights) with depgan_config.f32_split = 6 and 3."""
+    out = {"note": "opt-in (build_trainers(f32_split=6) / DEPGAN_F32_SPLIT=6), NOT the headline: every fp32 operand of the MFMA "
+                   "convolutions is split exactly into three bf16 terms (3 x 8 significand bits = fp32's 24) and the six "
+                   "largest of the nine cross products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; dropped terms "
+                   "are below 2^-24 |x||w|.  Operator error against float64 (tests/test_gpu_ops.py): six products 1.0e-7 - "
+                   "4.3e-7 mean relative, the native fp32 MFMA kernel 1.3e-7 - 5.0e-7 on the same shapes.  Weight gradients "
+                   "stay on the fp32 pipe."}
+    for mode in (6, 3):
+        nets = [dg.Gen_UNet2D((256, 256, 1), (32, 1), 32, 1, seed=1), dg.Dis_C2D_FCN1((256, 256, 1), seed=2),
+                dg.Dis_C2D_FCN1((256, 256, 1), seed=3)]
+        tr = dg.build_trainers(*nets, batchSize=B, device=dev, f32_split=mode)
+
+        def step():
+            tr.netD_y2_train([y2, x, z, ep])
+            tr.netD_dem_train([y2, x, z, ep])
+            tr.netG_train([x, y2, z])
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        eng = tr.engine
+        eng.profile(True)
+        eng.profile_reset()
+        step()
+        c_ms, _, c_fl = eng.profile_read(0)
+        w_ms, _, _ = eng.profile_read(1)
+        o_ms, _, _ = eng.profile_read(2)
+        eng.profile(False)
+        eng.profile_reset()
+        eng.g_forward(x, z)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            eng.g_forward(x, z)
+        torch.cuda.synchronize()
+        gf = (time.perf_counter() - t1) / 5 * 1e3
+        eng.close()
+        out["products_%d" % mode] = {
+            "ms_per_step": round(ms, 3), "slices_per_s": round(B / (ms * 1e-3), 1),
+            "ms_per_step_by_class": {"conv": round(c_ms, 3), "wgrad_fp32": round(w_ms, 3), "other": round(o_ms, 3)},
+            "conv_class_tflops_fp32_equivalent": round(c_fl / (c_ms * 1e-3) / 1e12, 1) if c_ms > 0 else 0.0,
+            "g_forward_ms": round(gf, 3)}
+    return out
+
+
 def bench_config5(dg, torch, dev, B, steps=5):
     """One Model.train_on_batch of DEP-UResNet (UT:602-606): phase-1 BatchNorm, Dropout, softmax + categorical CE, Adam."""
     rng = np.random.default_rng(5)
@@ -431,6 +482,11 @@ def main():
     config4 = None
     if world == 1 and rank == 0 and not os.environ.get("DEPGAN_BENCH_SKIP_CONFIG4"):
         config4 = bench_config4(dg, torch, dev, B)
+    # ---- extra, opt-in mode, never the headline: the SAME fp32 workload with the convolutions' fp32 operands split exactly
+    # into bf16 terms and the six largest cross products on the bf16 matrix pipe (depgan_config.f32_split = 6) ----
+    f32_split = None
+    if world == 1 and rank == 0 and not os.environ.get("DEPGAN_BENCH_SKIP_SPLIT") and not tr.engine.f32_split:
+        f32_split = bench_split(dg, torch, dev, B, x, y2, z, ep)
     # ---- extra: BASELINE configs[4], the DEP-UResNet supervised step (learning phase 1, softmax / CE head) ----
     config5 = None
     if world == 1 and rank == 0 and not os.environ.get("DEPGAN_BENCH_SKIP_CONFIG5"):
@@ -475,6 +531,8 @@ def main():
             line["config4"] = config4
         if config5 is not None:
             line["config5"] = config5
+        if f32_split is not None:
+            line["f32_split"] = f32_split
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -32,7 +32,8 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_int), ("batch", C.c_int), ("height", C.c_int), ("width", C.c_int),
                 ("nicg", C.c_int), ("first_fm", C.c_int), ("im_thresh", C.c_float), ("delta", C.c_float),
                 ("lrD", C.c_float), ("lrG", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-                ("adam_eps", C.c_float), ("nc_out", C.c_int), ("bf16_weights", C.c_int), ("bf16_mfma", C.c_int)]
+                ("adam_eps", C.c_float), ("nc_out", C.c_int), ("bf16_weights", C.c_int), ("bf16_mfma", C.c_int),
+                ("f32_split", C.c_int)]
 
     def __init__(self, **kw):
         super().__init__(**kw)

@@ -146,9 +146,14 @@ struct ConvPlan {
 ConvPlan dg_plan_conv(int KS, int Cin, int Cout);
 // the bf16 plan where the bf16 kernel covers the shape (Cout % 32 == 0, Cin >= 8), else the fp32 plan
 ConvPlan dg_plan_conv_bf16(int KS, int Cin, int Cout);
+// fp32 operands split into `planes` (2 or 3) bf16 terms each, 3 or 6 products on the bf16 pipe (igemm_split_kernel);
+// the plan's bf16 field then holds the number of planes and its packed layout is
+// [nt][cc][tap group][plane][tap][n][k = 16]
+ConvPlan dg_plan_conv_split(int KS, int Cin, int Cout, int planes);
 int dg_conv_igemm_bf16(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
 // byte size of one packed element of a plan
-static inline size_t dg_plan_elem_bytes(const ConvPlan& pl) { return pl.bf16 ? 2 : 4; }
+// bytes of packed storage per element of the plain [nt][cc][tap][n][k] panel (split plans store `bf16` planes of it)
+static inline size_t dg_plan_elem_bytes(const ConvPlan& pl) { return pl.variant >= 200 ? 2 * (size_t)pl.bf16 : (pl.bf16 ? 2 : 4); }
 
 // One weight-packing job of a batched launch (dg_pack_weights_batch): what dg_pack_weights takes, plus an optional
 // re-spacing of the channel-tile blocks in the destination (nt_stride elements between consecutive channel tiles;
@@ -159,7 +164,9 @@ struct PackJob {
   const float* kscale;
   int ntaps, srcI, srcO, io, transpose, flip;
   int NT, CK, nCC, Kdim, Ndim;
-  int bf16;             // 1: dst is a bf16 panel (elements of 2 bytes, RNE from the fp32 source x kscale)
+  int bf16;             // 1: dst is a bf16 panel (elements of 2 bytes, RNE from the fp32 source x kscale); 2 / 3: split
+                        // panel of that many planes (plane p = bf16 of what planes < p left over), TAPG taps per group
+  int tapg;             // split panels only: taps per staged group
   unsigned total;       // packed elements of this job
   unsigned per_nt;      // packed floats per channel tile (nCC * ntaps * NT * CK)
   unsigned nt_stride;   // destination elements between channel tiles

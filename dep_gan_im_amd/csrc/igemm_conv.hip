@@ -27,6 +27,19 @@ __device__ __forceinline__ void store_packed(float* dst, size_t i, float v, int 
   if (bf16) reinterpret_cast<__bf16*>(dst)[i] = (__bf16)v;
   else dst[i] = v;
 }
+// split panels (igemm_split_kernel): element (nt, cc, tap, n, k) of the plain layout goes to NPL planes at
+// [nt][cc][tap / tapg][plane][tap % tapg][n][k]; plane p holds bf16 of what the planes before it left over
+__device__ __forceinline__ void store_split(float* dst, size_t nt_base, int cc, int tap, int n, int k, float v, int planes,
+                                            int tapg, int ntaps, int NT, int CK) {
+  const int ng = ntaps / tapg, tg = tap / tapg, tl = tap - tg * tapg;
+  __bf16* d = reinterpret_cast<__bf16*>(dst) + nt_base + ((size_t)cc * ng + tg) * (size_t)(planes * tapg * NT * CK);
+  float rem = v;
+  for (int p = 0; p < planes; ++p) {
+    const __bf16 hb = (__bf16)rem;
+    d[((size_t)p * tapg + tl) * (NT * CK) + (size_t)n * CK + k] = hb;
+    rem -= (float)hb;
+  }
+}
 
 template <int MF>
 struct Mfma;
@@ -462,7 +475,7 @@ int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
 // ---------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int ntaps, int srcI,
                                     int srcO, int io, int transpose, int flip, const float* __restrict__ kscale,
-                                    int NT, int CK, int nCC, int Kdim, int Ndim, size_t total, int bf16) {
+                                    int NT, int CK, int nCC, int Kdim, int Ndim, size_t total, int bf16, int tapg) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t q = i;
     const int k = (int)(q % CK);
@@ -483,7 +496,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
       v = src[off];
       if (kscale) v *= kscale[kk];
     }
-    store_packed(dst, i, v, bf16);
+    if (bf16 >= 2) store_split(dst, (size_t)nt * nCC * ntaps * NT * CK * bf16, cc, tap, n, k, v, bf16, tapg, ntaps, NT, CK);
+    else store_packed(dst, i, v, bf16);
   }
 }
 
@@ -517,7 +531,10 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackJob* 
       v = J.src[off];
       if (J.kscale) v *= J.kscale[kk];
     }
-    store_packed(J.dst, (size_t)nt * J.nt_stride + (i - (unsigned)nt * J.per_nt), v, J.bf16);
+    if (J.bf16 >= 2)
+      store_split(J.dst, (size_t)nt * J.nt_stride * J.bf16, cc, tap, n, k, v, J.bf16, J.tapg, J.ntaps, J.NT, J.CK);
+    else
+      store_packed(J.dst, (size_t)nt * J.nt_stride + (i - (unsigned)nt * J.per_nt), v, J.bf16);
   }
 }
 
@@ -532,6 +549,7 @@ int dg_pack_job(const ConvPlan& pl, const float* src, int srcI, int srcO, int io
   job->ntaps = pl.KS * pl.KS; job->srcI = srcI; job->srcO = srcO; job->io = io; job->transpose = transpose;
   job->flip = flip; job->NT = pl.NT; job->CK = pl.CK; job->nCC = pl.nCC; job->Kdim = Kdim; job->Ndim = Ndim;
   job->bf16 = pl.bf16;
+  job->tapg = (pl.variant >= 200) ? (pl.KS == 5 ? 5 : pl.KS * pl.KS) : 0;
   job->total = (unsigned)((size_t)pl.nNT * pl.nCC * pl.KS * pl.KS * pl.NT * pl.CK);
   job->per_nt = (unsigned)((size_t)pl.nCC * pl.KS * pl.KS * pl.NT * pl.CK);
   job->nt_stride = nt_stride ? (unsigned)nt_stride : job->per_nt;
@@ -569,7 +587,8 @@ int dg_pack_weights(const ConvPlan& pl, const float* src, int srcI, int srcO, in
   const size_t total = (size_t)pl.nNT * pl.nCC * pl.KS * pl.KS * pl.NT * pl.CK;
   const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, st, src, dst, pl.KS * pl.KS, srcI, srcO, io,
-                     transpose, flip, kscale, pl.NT, pl.CK, pl.nCC, Kdim, Ndim, total, pl.bf16);
+                     transpose, flip, kscale, pl.NT, pl.CK, pl.nCC, Kdim, Ndim, total, pl.bf16,
+                     (pl.variant >= 200) ? (pl.KS == 5 ? 5 : pl.KS * pl.KS) : 0);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }

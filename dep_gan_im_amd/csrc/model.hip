@@ -98,6 +98,7 @@ static int net_requantize(depgan_ctx* c, Net& n) {
 
 // the plan of one convolution of this context: bf16 matrix pipe where configured and covered, else fp32
 static ConvPlan plan_conv(const depgan_ctx* c, int KS, int Cin, int Cout) {
+  if (c->cfg.f32_split) return dg_plan_conv_split(KS, Cin, Cout, c->cfg.f32_split == 6 ? 3 : 2);
   return c->cfg.bf16_mfma ? dg_plan_conv_bf16(KS, Cin, Cout) : dg_plan_conv(KS, Cin, Cout);
 }
 
@@ -109,8 +110,9 @@ int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
   const int ng = a.groups > 1 ? a.groups : 1;
   const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cin * a.Cout * KS * KS * ng;
   char lb[56];
-  snprintf(lb, sizeof(lb), "conv%s k%d b%d %dx%d %d->%d%s", pl.bf16 ? "(bf16)" : "", KS, a.B, a.H, a.W, a.Cin, a.Cout,
-           ng > 1 ? " x4" : "");
+  snprintf(lb, sizeof(lb), "conv%s k%d b%d %dx%d %d->%d%s",
+           pl.variant >= 200 ? (pl.bf16 == 3 ? "(bf16x6)" : "(bf16x3)") : (pl.bf16 ? "(bf16)" : ""), KS, a.B, a.H, a.W, a.Cin,
+           a.Cout, ng > 1 ? " x4" : "");
   // algorithmic bytes: every operand the epilogue names read once, every result written once, weights once
   const double px = 4.0 * a.B * a.H * a.W;
   const double by = px * a.Cin + ng * (px * a.Cout * (1 + (a.ep.res.p ? 1 : 0) + (a.ep.mask.p ? 1 : 0) +
@@ -1112,6 +1114,11 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
                  (int)sizeof(depgan_config));
     return DG_ERR_ARG;
   }
+  if (cfg->f32_split != 0 && ((cfg->f32_split != 3 && cfg->f32_split != 6) || cfg->bf16_weights || cfg->bf16_mfma ||
+                               (cfg->nc_out != 0 && cfg->nc_out != 1))) {
+    dg_set_error("depgan_create: f32_split must be 0, 3 or 6, without bf16_weights / bf16_mfma, nc_out = 1");
+    return DG_ERR_ARG;
+  }
   if (cfg->bf16_mfma && (!cfg->bf16_weights || (cfg->nc_out != 0 && cfg->nc_out != 1))) {
     dg_set_error("depgan_create: bf16_mfma needs bf16_weights = 1 and the DEP-GAN generator (nc_out = 1)");
     return DG_ERR_ARG;
@@ -1452,8 +1459,9 @@ static int op_conv(const float* in, const float* w_hwio, const float* bias, floa
   a.B = B; a.H = H; a.W = W; a.Cin = ci; a.Cout = co;
   a.ep.bias = bias;
   a.ep.relu = relu;
-  ConvPlan pl = (path == 3) ? dg_plan_conv_bf16(KS, ci, co) : dg_plan_conv(KS, ci, co);
-  if (path == 3 && !pl.bf16) { dg_set_error("op_conv: the bf16 MFMA kernel does not cover this shape"); return DG_ERR_UNSUPPORTED; }
+  ConvPlan pl = (path == 3) ? dg_plan_conv_bf16(KS, ci, co)
+                : (path == 4 || path == 5) ? dg_plan_conv_split(KS, ci, co, path == 5 ? 3 : 2) : dg_plan_conv(KS, ci, co);
+  if (path >= 3 && !pl.bf16) { dg_set_error("op_conv: the bf16 MFMA kernel does not cover this shape"); return DG_ERR_UNSUPPORTED; }
   if (path == 1 && pl.variant < 0) { dg_set_error("op_conv: MFMA path not available for this shape"); return DG_ERR_UNSUPPORTED; }
   if (path != 2 && pl.variant >= 0) {
     float* wp = nullptr;

@@ -8,6 +8,7 @@ handle only; every FLOP runs in the hand-written HIP kernels behind the C ABI
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -27,16 +28,22 @@ def _torch():
 class Engine:
     def __init__(self, batch, height=256, width=256, nicg=1, first_fm=32, im_thresh=0.5, delta=10.0, lrD=1e-4,
                  lrG=1e-4, beta1=0.0, beta2=0.9, adam_eps=1e-7, device=None, nc_out=1, bf16_weights=False,
-                 bf16_mfma=False):
+                 bf16_mfma=False, f32_split=0):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.DepganError("dep_gan_im_amd needs a ROCm GPU (MI355X): torch.cuda.is_available() is False")
         self.lib = load()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         torch.cuda.set_device(self.device)
+        if not f32_split and not (bf16_weights or bf16_mfma) and nc_out == 1:
+            # DEPGAN_F32_SPLIT=6 (or 3) turns the opt-in split-product convolutions on for contexts that do not ask for
+            # anything else: lets the whole parity suite / bench run on them unchanged
+            f32_split = int(os.environ.get("DEPGAN_F32_SPLIT", "0") or 0)
+        self.f32_split = int(f32_split)
         self.cfg = Config(batch=batch, height=height, width=width, nicg=nicg, first_fm=first_fm, im_thresh=im_thresh,
                           delta=delta, lrD=lrD, lrG=lrG, beta1=beta1, beta2=beta2, adam_eps=adam_eps, nc_out=nc_out,
-                          bf16_weights=1 if (bf16_weights or bf16_mfma) else 0, bf16_mfma=1 if bf16_mfma else 0)
+                          bf16_weights=1 if (bf16_weights or bf16_mfma) else 0, bf16_mfma=1 if bf16_mfma else 0,
+                          f32_split=int(f32_split))
         self.batch, self.height, self.width, self.nicg, self.nc_out = batch, height, width, nicg, nc_out
         h = C.c_void_p()
         check(self.lib.depgan_create(C.byref(self.cfg), C.byref(h)), "depgan_create")

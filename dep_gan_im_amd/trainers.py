@@ -123,7 +123,7 @@ class Trainers:
 
 
 def build_trainers(netG, netD_y2, netD_dem, batchSize=16, delta=10.0, lrD=1e-4, lrG=1e-4, IM_TRSH=0.5,
-                   dist=None, device=None, weights_dtype="float32", activations_dtype="float32"):
+                   dist=None, device=None, weights_dtype="float32", activations_dtype="float32", f32_split=0):
     """Builds the loss graph of GT:523-598 for the three models and returns a
     Trainers object.  The models are bound to one engine: afterwards their
     predict()/get_weights()/save() see the trained weights.
@@ -131,6 +131,8 @@ def build_trainers(netG, netD_y2, netD_dem, batchSize=16, delta=10.0, lrD=1e-4, 
     fp32 master weights and Adam state; get_weights() returns the fp32 masters.
     activations_dtype="bfloat16" (needs bf16 weights): the MFMA convolutions also round their activation operand to
     bf16 and run on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16), accumulating in fp32.
+    f32_split=6 (or 3): opt-in -- fp32 operands of the MFMA convolutions split exactly into three (two) bf16 terms, the six
+    (three) largest cross products on the bf16 matrix pipe, fp32 accumulation (include/depgan.h, depgan_config.f32_split).
     dist: a dep_gan_im_amd.dist.DataParallel -- the engine becomes one replica of a data-parallel job (rank 0's
     weights are broadcast, every update all-reduces its gradient arena)."""
     if weights_dtype not in ("float32", "bfloat16"):
@@ -144,7 +146,7 @@ def build_trainers(netG, netD_y2, netD_dem, batchSize=16, delta=10.0, lrD=1e-4, 
         raise ValueError("critics must take (%d,%d,1) images" % (H, W))
     eng = Engine(batchSize, H, W, nicg, first_fm=netG.first_fm, im_thresh=IM_TRSH, delta=delta, lrD=lrD, lrG=lrG,
                  beta1=0.0, beta2=0.9, device=device, bf16_weights=(weights_dtype == "bfloat16"),
-                 bf16_mfma=(activations_dtype == "bfloat16"))
+                 bf16_mfma=(activations_dtype == "bfloat16"), f32_split=f32_split)
     netG._bind(eng, "G")
     netD_y2._bind(eng, "D_y2")
     netD_dem._bind(eng, "D_dem")

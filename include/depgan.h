@@ -48,6 +48,11 @@ typedef struct depgan_config {
   int bf16_mfma;    /* BASELINE config 4 on the bf16 matrix pipe (needs bf16_weights = 1): the MFMA convolutions round
                        their activation operand to bf16 (RNE) while staging it and run v_mfma_f32_32x32x16_bf16 with
                        fp32 accumulation; everything between the convolutions stays fp32.  0 = fp32 matrix pipe  */
+  int f32_split;    /* 0 (default): fp32 products on v_mfma_f32_32x32x2_f32.  6 or 3 (opt-in, never the benchmark's
+                       headline; excludes bf16_weights / bf16_mfma): every fp32 operand of the MFMA convolutions is split
+                       exactly into three (two) bf16 terms and the six (three) largest cross products run on
+                       v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- dropped terms are below 2^-24 (2^-16) of
+                       |x||w|, i.e. fp32-grade (6) or TF32-grade-plus (3) products at 2.7x (5.3x) the fp32 matrix rate */
 } depgan_config;
 
 enum { DEPGAN_NET_G = 0, DEPGAN_NET_D_Y2 = 1, DEPGAN_NET_D_DEM = 2 };
@@ -194,7 +199,8 @@ int depgan_data_prep_subject(const float* p1_dev, const float* f1_dev, const flo
                              int nicg, float* x_out_dev, float* y2_out_dev, float* scratch_dev, void* stream);
 
 /* ---- single operators (unit-test surface; device pointers) ---- */
-/* path: 0 auto, 1 fp32 MFMA implicit GEMM, 2 direct, 3 bf16 MFMA implicit GEMM (both operands rounded to bf16, RNE) */
+/* path: 0 auto, 1 fp32 MFMA implicit GEMM, 2 direct, 3 bf16 MFMA implicit GEMM (both operands rounded to bf16, RNE),
+ * 4 / 5: fp32 operands split into 2 / 3 bf16 terms, 3 / 6 products on the bf16 pipe (depgan_config.f32_split = 3 / 6) */
 int depgan_op_conv2d(const float* in, const float* w_hwio, const float* bias, float* out, int B, int H, int W,
                      int Cin, int Cout, int KS, int relu, int path, void* hip_stream);
 int depgan_op_conv2d_bwd_data(const float* dy, const float* w_hwio, float* dx, int B, int H, int W, int Cin,

@@ -108,6 +108,50 @@ def test_bf16_mfma_conv_forward_and_backward_data(lib, case):
     assert lib.depgan_op_conv2d(P(xd), P(wd), P(bd), P(out), B, H, W, ci, 16, k, 1, 3, None) != 0   # refused before any launch
 
 
+SPLIT_CASES = [(2, 32, 32, 32, 32, 3), (2, 48, 40, 32, 64, 3), (1, 32, 32, 224, 96, 3), (2, 21, 19, 64, 160, 3),
+               (2, 32, 32, 16, 32, 5), (2, 17, 33, 32, 64, 5), (2, 32, 32, 128, 128, 1), (1, 16, 16, 256, 256, 3),
+               (2, 30, 18, 8, 32, 3), (2, 32, 32, 48, 96, 3)]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_split_bf16_conv_is_fp32_grade(lib, case):
+    """depgan_config.f32_split (opt-in): fp32 operands split exactly into bf16 terms, the largest cross products on the
+    bf16 matrix pipe, fp32 accumulation.  Against the float64 reference of the UNROUNDED operands: six products must be
+    as accurate as the native fp32 MFMA kernel (same tolerance, errors printed side by side), three products within
+    2^-16-sized terms."""
+    from dep_gan_im_amd import _lib
+    B, H, W, ci, co, k = case
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(ci * 1000 + co + k)
+    x = rng.standard_normal((B, H, W, ci)).astype(np.float32)
+    w = (rng.standard_normal((k, k, ci, co)) / np.sqrt(k * k * ci)).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, co)).astype(np.float32)
+    xd, wd, bd, dyd = [torch.from_numpy(a).to(dev) for a in (x, w, b, dy)]
+    ref = _ref_conv(x, w, b, True)
+    errs = {}
+    for name, path in (("native", 1), ("x3", 4), ("x6", 5)):
+        out = torch.full((B, H, W, co), float("nan"), device=dev)
+        _lib.check(lib.depgan_op_conv2d(P(xd), P(wd), P(bd), P(out), B, H, W, ci, co, k, 1, path, None))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().astype(np.float64)
+        errs[name] = (rel(got, ref), float(np.abs(got - ref).mean() / np.abs(ref).mean()))
+    print("k%d %d->%d: max-rel / mean-rel error vs fp64: native %.1e / %.1e, six products %.1e / %.1e, three %.1e / %.1e"
+          % ((k, ci, co) + errs["native"] + errs["x6"] + errs["x3"]))
+    assert errs["native"][0] < TOL and errs["x6"][0] < TOL
+    assert errs["x6"][1] < 4 * errs["native"][1] + 1e-7           # fp32-grade: the same order as the native pipe
+    assert errs["x3"][0] < 3e-4 and errs["x3"][1] < 2e-5
+    if ci % 32 == 0:
+        xt = torch.from_numpy(x).permute(0, 3, 1, 2).double().requires_grad_(True)
+        y = F.conv2d(xt, torch.from_numpy(w).permute(3, 2, 0, 1).double(), padding=k // 2)
+        (gx,) = torch.autograd.grad(y, xt, torch.from_numpy(dy).permute(0, 3, 1, 2).double())
+        for path in (4, 5):
+            dx = torch.full((B, H, W, ci), float("nan"), device=dev)
+            _lib.check(lib.depgan_op_conv2d_bwd_data(P(dyd), P(wd), P(dx), B, H, W, ci, co, k, path, None))
+            torch.cuda.synchronize()
+            assert rel(dx.cpu().numpy(), gx.permute(0, 2, 3, 1).numpy()) < (TOL if path == 5 else 3e-4)
+
+
 WGRAD_CASES = [(2, 32, 32, 32, 32, 3), (3, 48, 40, 64, 64, 3), (2, 23, 17, 96, 32, 3), (2, 16, 16, 256, 256, 3),
                (2, 32, 32, 16, 16, 5), (2, 32, 32, 16, 32, 5), (2, 32, 24, 32, 32, 5), (2, 32, 32, 128, 128, 1),
                (2, 32, 32, 1, 32, 3), (2, 32, 32, 2, 32, 3), (2, 32, 32, 1, 16, 5), (4, 64, 64, 32, 64, 3),
