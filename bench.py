@@ -13,6 +13,12 @@ anything touches HIP, relays rank 0's JSON line and exits with the child's
 status.  --dry-run replaces the GPU engine by a host stand-in and RCCL by gloo
 so that the launcher / rank plumbing can be rehearsed on a machine without GPUs.
 
+Extra objects on the same line at N = 1 (each builds an engine of its own after the timed region, none is the headline):
+  config4:   BASELINE configs[3] on the bf16 matrix pipe (256x256x2, bf16 weights and activations, fp32 accumulate)
+  config5:   BASELINE configs[4], the DEP-UResNet supervised step
+  f32_split: the headline workload with the opt-in split-product convolutions (fp32 operands as exact sums of bf16
+             terms, six / three cross products on the bf16 pipe)
+
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline:     MFMA implicit-GEMM convolution class (dominant kernels) --
                 algorithmic FLOPs / HIP-event time, measured live on extra steps

@@ -389,10 +389,12 @@ ConvPlan dg_plan_conv_bf16(int KS, int Cin, int Cout) {
   return p;
 }
 
-// split plans: bf16 = number of planes (2 or 3); Cout a multiple of 32, Cin a multiple of 4 and >= 8 like the bf16 plans
+// split plans: bf16 = number of planes (2 or 3); Cin a multiple of 4 and >= 8 like the bf16 plans; Cout a multiple of 16 --
+// a 16-channel layer (the critics' first 5x5 convolutions) runs as half of a 32-channel tile with zero weight rows: twice
+// the MFMAs it needs, still a third of the cycles the fp32 pipe's 16x16x4 form takes for it
 ConvPlan dg_plan_conv_split(int KS, int Cin, int Cout, int planes) {
   ConvPlan p = dg_plan_conv(KS, Cin, Cout);
-  if (p.variant < 0 || (Cout % 32) != 0 || Cin < 8 || (Cin % 4) != 0 || !(KS == 1 || KS == 3 || KS == 5) ||
+  if (p.variant < 0 || (Cout % 16) != 0 || Cin < 8 || (Cin % 4) != 0 || !(KS == 1 || KS == 3 || KS == 5) ||
       (planes != 2 && planes != 3))
     return p;
   p.bf16 = planes;
