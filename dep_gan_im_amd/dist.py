@@ -78,8 +78,20 @@ class DataParallel:
         return t
 
     def allreduce_ptr(self, ptr, n, stream=0):
-        t = self._view(ptr, n)
         self.calls += 1
+        if not self.on_device and self.device is not None and getattr(self.device, "type", "cpu") == "cuda":
+            # gloo group around GPU engines (tests: two ranks sharing one GPU, where RCCL refuses to run): the message is
+            # staged through the host.  Synchronises the stream -- a test path, not the product's.
+            key = ("dev", ptr, n)
+            t = self._views.get(key)
+            if t is None:
+                t = self._views[key] = torch.as_tensor(_DevArray(ptr, n), device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return
+        t = self._view(ptr, n)
         if self.on_device:
             cur = torch.cuda.current_stream(self.device)
             if stream and cur.cuda_stream != stream:    # the engine was put on another stream: order against THAT one
@@ -98,7 +110,7 @@ class DataParallel:
             for arena in (ARENA_PARAMS, ARENA_NONTRAINABLE, ARENA_ADAM_M, ARENA_ADAM_V):
                 ptr, n = engine.arena(net, arena)
                 if n:
-                    dist.broadcast(self._view(ptr, n), src=self._global_rank0(), group=self.group)
+                    self._broadcast_ptr(ptr, n)
             t = torch.tensor([engine.adam_step(net)], dtype=torch.int64,
                              device=self.device if self.on_device else None)
             dist.broadcast(t, src=self._global_rank0(), group=self.group)
@@ -106,6 +118,16 @@ class DataParallel:
             engine.weights_changed(net)
         engine.set_allreduce(self.allreduce_ptr, self.world)
         return engine
+
+    def _broadcast_ptr(self, ptr, n):
+        if not self.on_device and self.device is not None and getattr(self.device, "type", "cpu") == "cuda":
+            t = torch.as_tensor(_DevArray(ptr, n), device=self.device)       # gloo around GPU engines: via the host
+            torch.cuda.synchronize(self.device)
+            h = t.cpu()
+            dist.broadcast(h, src=self._global_rank0(), group=self.group)
+            t.copy_(h)
+            return
+        dist.broadcast(self._view(ptr, n), src=self._global_rank0(), group=self.group)
 
     def _global_rank0(self):
         return dist.get_global_rank(self.group, 0) if self.group is not None else 0

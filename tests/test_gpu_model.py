@@ -550,3 +550,83 @@ def test_other_generator_widths_fail_loudly(lib):
     from dep_gan_im_amd import DepganError, Engine
     with pytest.raises(DepganError, match="first_fm"):
         Engine(2, 64, 64, 1, first_fm=16)
+
+
+def _dp_rank(rank, world, port, q, payload):
+    """One data-parallel rank with a REAL engine (gloo group: two ranks may share one GPU, RCCL may not)."""
+    import torch.distributed as dist
+    import dep_gan_im_amd as dg
+    from dep_gan_im_amd.dist import DataParallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        img, B, P, x, y2, z, ep, zs = payload
+        lo, hi = rank * B, (rank + 1) * B
+        # replicas start from DIFFERENT weights: attach() must make them rank 0's
+        nets = [dg.Gen_UNet2D((img, img, 1), seed=10 + rank), dg.Dis_C2D_FCN1((img, img, 1), seed=20 + rank),
+                dg.Dis_C2D_FCN1((img, img, 1), seed=30 + rank)]
+        if rank == 0:
+            for n, Pn in zip(nets, P):
+                n.set_weights(Pn)
+        tr = dg.build_trainers(*nets, batchSize=B, dist=DataParallel())
+        xs, ys, zz, ee = x[lo:hi], y2[lo:hi], z[lo:hi], ep[lo:hi]
+        outs = tr.netD_y2_train([ys, xs, zz, ee]) + tr.netD_dem_train([ys, xs, zz, ee]) + tr.netG_no_update([xs, ys, zz]) \
+            + tr.netG_train([xs, ys, zz])
+        cy, cd, ev, g6, best = tr.gen_iteration((xs, ys, zz[None], ee[None], 1), (xs, ys, zz[None], ee[None], 1),
+                                                (xs, ys, zs[:, lo:hi]))
+        outs = outs + cy[0] + cd[0] + [v for e in ev for v in e] + g6 + [float(best)]
+        q.put((rank, outs, [n.get_weights_dict() for n in nets], tr.dist.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_real_ranks_equal_one_process_on_the_global_batch(lib):
+    """Data parallelism end to end with two REAL engines (two processes sharing this GPU, gloo instead of RCCL, the
+    library's hook protocol unchanged): replicas built from different seeds are made identical by attach(), every
+    closure and the one-call generator iteration report the GLOBAL scalars on both ranks, the replicas stay bitwise
+    identical through four updates each, and all of it equals ONE process fed the global batch."""
+    import socket
+    import torch.multiprocessing as mp
+    import dep_gan_im_amd as dg
+    img, B, world = 64, 2, 2
+    PG, PD1, PD2, x, y2, z, ep = _setup(img, B * world, 71, noisy=True)
+    zs = np.random.default_rng(3).normal(size=(3, B * world, 32, 1)).astype(np.float32)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    payload = (img, B, (PG, PD1, PD2), x, y2, z, ep, zs)
+    procs = [ctx.Process(target=_dp_rank, args=(r, world, port, q, payload)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # one process, global batch
+    nets = [dg.Gen_UNet2D((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1))]
+    for n, Pn in zip(nets, (PG, PD1, PD2)):
+        n.set_weights(Pn)
+    tr = dg.build_trainers(*nets, batchSize=B * world)
+    want = tr.netD_y2_train([y2, x, z, ep]) + tr.netD_dem_train([y2, x, z, ep]) + tr.netG_no_update([x, y2, z]) \
+        + tr.netG_train([x, y2, z])
+    cy, cd, ev, g6, best = tr.gen_iteration((x, y2, z[None], ep[None], 1), (x, y2, z[None], ep[None], 1), (x, y2, zs))
+    want = want + cy[0] + cd[0] + [v for e in ev for v in e] + g6 + [float(best)]
+    assert res[0][1] == res[1][1]                                    # identical scalars on both ranks (same arg-min)
+    assert res[0][3] == res[1][3] == 8                               # one collective per update / evaluation
+    for a_, b_ in zip(res[0][2], res[1][2]):                         # replicas bitwise identical after 4 updates each
+        for k in a_:
+            np.testing.assert_array_equal(a_[k], b_[k])
+    # vs the single process: the first 16 scalars come from identical weights -> summation order only
+    np.testing.assert_allclose(res[0][1][:16], want[:16], rtol=2e-4, atol=1e-6)
+    # later ones follow Adam steps (+-lr per element, a rounding-sized gradient may flip): same yardstick as the
+    # single-process closure test
+    assert srel(res[0][1][16:-1], want[16:-1]) < 1e-2
+    single = [n.get_weights_dict() for n in nets]
+    for a_, b_ in zip(res[0][2], single):
+        assert max(float(np.abs(a_[k] - b_[k]).max()) for k in a_) <= 2 * 2.2e-4
+        frac = np.mean([np.mean(np.abs(a_[k] - b_[k]) > 1e-5) for k in a_ if k.endswith("kernel")])
+        assert frac < 0.05, frac
