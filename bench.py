@@ -385,6 +385,11 @@ def main():
     from dep_gan_im_amd.build import build
     build()
 
+    # DEPGAN_BENCH_ONE_GPU=1: rehearsal of the multi-rank path on a box with ONE GPU -- every rank uses cuda:0 and the group
+    # is gloo (RCCL refuses two ranks on one device); the slices/s of such a run mean nothing, the plumbing is what runs
+    one_gpu = bool(os.environ.get("DEPGAN_BENCH_ONE_GPU"))
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda:%d" % local)
     dp = None
@@ -392,7 +397,10 @@ def main():
         import torch.distributed as dist
         from dep_gan_im_amd.dist import DataParallel
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         dp = DataParallel()
 
     B = args.batch
@@ -423,7 +431,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dp is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=None if one_gpu else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
@@ -523,7 +531,7 @@ def main():
         line = {"metric": "2D slices/sec (G+2D+GP train step), 256x256x1 fp32", "value": round(value, 3),
                 "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
+                "dtype": "f32", "data": "synthetic" if not one_gpu else "synthetic; REHEARSAL: all ranks on one GPU, gloo",
                 "config": {"workload": "DEP-GAN-IM twoCritics canonical train step (critic-Y2 + critic-DEM + G update, "
                                        "WGAN-GP), batch %d per GPU, 256x256x1" % B,
                            "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world},
