@@ -144,6 +144,8 @@ struct ConvPlan {
                 // bf16 while it is staged, accumulation stays fp32
 };
 ConvPlan dg_plan_conv(int KS, int Cin, int Cout);
+// ... knowing the number of work items of its launches (chunk size by launch size, see igemm_conv.hip)
+ConvPlan dg_plan_conv_items(int KS, int Cin, int Cout, long items);
 // the bf16 plan where the bf16 kernel covers the shape (Cout % 32 == 0, Cin >= 8), else the fp32 plan
 ConvPlan dg_plan_conv_bf16(int KS, int Cin, int Cout);
 // fp32 operands split into `planes` (2 or 3) bf16 terms each, 3 or 6 products on the bf16 pipe (igemm_split_kernel);

@@ -67,7 +67,7 @@ struct Mfma<16> {
 // the loop (that is the point), which costs ~36 VGPRs and one resident workgroup per CU -- wrong for launches that
 // run one item per workgroup.
 template <int MF, int KS, int CK, int TAPG, bool PERS>
-__global__ __launch_bounds__(256, (PERS && KS == 3) ? 3 : 1) void igemm_conv_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (PERS && KS == 3) ? (CK == 8 ? 4 : 3) : 1) void igemm_conv_kernel(const ConvArgs a) {
   constexpr int NT = MF;
   constexpr int PAD = KS / 2;
   constexpr int TW = 16 + KS - 1;
@@ -384,6 +384,24 @@ ConvPlan dg_plan_conv(int KS, int Cin, int Cout) {
   return p;
 }
 
+// The plan of a 3x3 convolution whose launches have `items` work items (pixel tiles x channel tiles at the batch it
+// mostly runs at).  Large launches take 8-channel chunks: 29 KB of LDS and 124 VGPRs let FOUR workgroups share a CU
+// instead of three -- one more wave per SIMD to run while the older ones stall -- at twice the chunk boundaries per item.
+// Measured (profiles/r02_conv_experiments.md): -1.2 ... -1.9 % time from 1536 items up, +1 ... +3 % below
+// (DEPGAN_IGEMM_CK8=0 keeps 16-channel chunks everywhere).
+ConvPlan dg_plan_conv_items(int KS, int Cin, int Cout, long items) {
+  ConvPlan p = dg_plan_conv(KS, Cin, Cout);
+  const char* e = getenv("DEPGAN_IGEMM_CK8");
+  const bool on = !(e && atoi(e) == 0);
+  if (on && p.variant == 0 && KS == 3 && p.MF == 32 && (Cin % 8) == 0 && items >= 1536) {
+    p.variant = 8;
+    p.CK = 8;
+    p.nCC = cdiv(Cin, p.CK);
+    p.packedFloats = (size_t)p.nNT * p.nCC * KS * KS * p.NT * p.CK;
+  }
+  return p;
+}
+
 template <int MF, int KS, int CK, int TAPG>
 static int launch_variant(const ConvArgs& a, hipStream_t st) {
   constexpr int TW = 16 + KS - 1;
@@ -414,7 +432,7 @@ static int launch_variant(const ConvArgs& a, hipStream_t st) {
     // the 3x3 persistent instantiation is compiled for 3 resident workgroups per CU; the others take what their
     // registers allow (2)
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > (KS == 3 ? 3 : 2)) per_cu = (KS == 3 ? 3 : 2);
+    if (per_cu > (KS == 3 ? (CK == 8 ? 4 : 3) : 2)) per_cu = (KS == 3 ? (CK == 8 ? 4 : 3) : 2);
     if (KS == 1) per_cu = 0;   // K is one chunk: nothing to amortise, measured -0.17 ms per step when persistent
     if (e) per_cu = atoi(e) < per_cu ? atoi(e) : per_cu;
     const long cap = 256L * per_cu;
@@ -466,6 +484,7 @@ int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
     case 3: return launch_variant<16, 5, 16, 25>(a, st);
     case 4: return launch_variant<32, 1, 32, 1>(a, st);
     case 5: return launch_variant<16, 1, 16, 1>(a, st);
+    case 8: return launch_variant<32, 3, 8, 9>(a, st);
   }
   return DG_ERR_UNSUPPORTED;
 }

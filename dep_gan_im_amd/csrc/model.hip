@@ -97,9 +97,15 @@ static int net_requantize(depgan_ctx* c, Net& n) {
 }
 
 // the plan of one convolution of this context: bf16 matrix pipe where configured and covered, else fp32
-static ConvPlan plan_conv(const depgan_ctx* c, int KS, int Cin, int Cout) {
+// N, H, W: the batch and spatial size the layer is planned for (they fix the number of work items of its launches).  N
+// is BASELINE's batch (32; 96 for the critics' [real | fake | mixed] passes), NOT the context's: the chunk size decides
+// the summation order, and a sample's result must not depend on how many samples share its batch
+// (test_bench_size_properties_batch32_256 checks batch 32 against four batches of 8 bit for bit).
+static ConvPlan plan_conv(const depgan_ctx* c, int KS, int Cin, int Cout, int N = 0, int H = 0, int W = 0) {
   if (c->cfg.f32_split) return dg_plan_conv_split(KS, Cin, Cout, c->cfg.f32_split == 6 ? 3 : 2);
-  return c->cfg.bf16_mfma ? dg_plan_conv_bf16(KS, Cin, Cout) : dg_plan_conv(KS, Cin, Cout);
+  if (c->cfg.bf16_mfma) return dg_plan_conv_bf16(KS, Cin, Cout);
+  const long items = (long)N * cdiv(H, 16) * cdiv(W, 16) * cdiv(Cout, 32);
+  return dg_plan_conv_items(KS, Cin, Cout, items);
 }
 
 // ---------------------------------------------------------------------------
@@ -395,8 +401,8 @@ static int build_generator(depgan_ctx* c) {
       L.s = take(L.Cout); L.t = take(L.Cout); L.rstd = take(L.Cout);
     }
     if (e.kind == G_CONV) {
-      L.pf = plan_conv(c, 3, L.Cin, L.Cout);
-      L.pb = plan_conv(c, 3, L.Cout, L.Cin);
+      L.pf = plan_conv(c, 3, L.Cin, L.Cout, 32, H, W);
+      L.pb = plan_conv(c, 3, L.Cout, L.Cin, 32, H, W);
       if (L.pf.variant >= 0) DGCHECK(dmalloc(c, &L.wpf[0], L.pf.packedFloats));
       if (i > 0 && L.pb.variant >= 0) DGCHECK(dmalloc(c, &L.wpb[0], L.pb.packedFloats));
       const bool skip = (i + 1 < kNTrunk && kTrunk[i + 1].kind == G_POOL);
@@ -417,8 +423,8 @@ static int build_generator(depgan_ctx* c) {
       }
       cur = L.out;
     } else if (e.kind == G_FILM) {
-      L.pf = plan_conv(c, 3, L.Cin, L.Cout);
-      L.pb = plan_conv(c, 3, L.Cout, L.Cin);
+      L.pf = plan_conv(c, 3, L.Cin, L.Cout, 32, H, W);
+      L.pb = plan_conv(c, 3, L.Cout, L.Cin, 32, H, W);
       DGCHECK(dmalloc(c, &L.wpf[0], L.pf.packedFloats));
       DGCHECK(dmalloc(c, &L.wpb[0], L.pb.packedFloats));
       const std::string key = e.aux;
@@ -507,8 +513,8 @@ static int build_critics(depgan_ctx* c) {
     L.pool = kDis[l].pool;
     L.H = H;
     L.W = W;
-    L.pf = plan_conv(c, L.KS, L.Cin, L.Cout);
-    L.pb = plan_conv(c, L.KS, L.Cout, L.Cin);
+    L.pf = plan_conv(c, L.KS, L.Cin, L.Cout, 96, H, W);     // the critics mostly run on [real | fake | mixed]
+    L.pb = plan_conv(c, L.KS, L.Cout, L.Cin, 96, H, W);
     DGCHECK(talloc(c, &c->d_act[l], c->NB3, H, W, L.Cout));
     DGCHECK(talloc(c, &c->d_dz[l], c->NB3, H, W, L.Cout));
     if (L.pool) {
@@ -1460,8 +1466,10 @@ static int op_conv(const float* in, const float* w_hwio, const float* bias, floa
   a.ep.bias = bias;
   a.ep.relu = relu;
   ConvPlan pl = (path == 3) ? dg_plan_conv_bf16(KS, ci, co)
-                : (path == 4 || path == 5) ? dg_plan_conv_split(KS, ci, co, path == 5 ? 3 : 2) : dg_plan_conv(KS, ci, co);
-  if (path >= 3 && !pl.bf16) { dg_set_error("op_conv: the bf16 MFMA kernel does not cover this shape"); return DG_ERR_UNSUPPORTED; }
+                : (path == 4 || path == 5) ? dg_plan_conv_split(KS, ci, co, path == 5 ? 3 : 2)
+                : (path == 6) ? dg_plan_conv_items(KS, ci, co, 1L << 30) : dg_plan_conv(KS, ci, co);
+  if (path == 6 && pl.CK != 8) { dg_set_error("op_conv: the 8-channel-chunk variant does not cover this shape"); return DG_ERR_UNSUPPORTED; }
+  if (path >= 3 && path <= 5 && !pl.bf16) { dg_set_error("op_conv: the bf16 MFMA kernel does not cover this shape"); return DG_ERR_UNSUPPORTED; }
   if (path == 1 && pl.variant < 0) { dg_set_error("op_conv: MFMA path not available for this shape"); return DG_ERR_UNSUPPORTED; }
   if (path != 2 && pl.variant >= 0) {
     float* wp = nullptr;

@@ -200,7 +200,8 @@ int depgan_data_prep_subject(const float* p1_dev, const float* f1_dev, const flo
 
 /* ---- single operators (unit-test surface; device pointers) ---- */
 /* path: 0 auto, 1 fp32 MFMA implicit GEMM, 2 direct, 3 bf16 MFMA implicit GEMM (both operands rounded to bf16, RNE),
- * 4 / 5: fp32 operands split into 2 / 3 bf16 terms, 3 / 6 products on the bf16 pipe (depgan_config.f32_split = 3 / 6) */
+ * 4 / 5: fp32 operands split into 2 / 3 bf16 terms, 3 / 6 products on the bf16 pipe (depgan_config.f32_split = 3 / 6),
+ * 6: fp32 MFMA with 8-channel chunks (what large 3x3 launches take) */
 int depgan_op_conv2d(const float* in, const float* w_hwio, const float* bias, float* out, int B, int H, int W,
                      int Cin, int Cout, int KS, int relu, int path, void* hip_stream);
 int depgan_op_conv2d_bwd_data(const float* dy, const float* w_hwio, float* dx, int B, int H, int W, int Cin,

@@ -32,6 +32,9 @@ CONV_CASES = [  # B,H,W,Cin,Cout,k,path
     (2, 32, 32, 32, 32, 3, 1), (2, 48, 40, 32, 64, 3, 1), (1, 32, 32, 224, 96, 3, 1), (2, 21, 19, 64, 160, 3, 1),
     (2, 32, 32, 16, 16, 5, 1), (2, 32, 32, 16, 32, 5, 1), (2, 32, 32, 32, 32, 5, 1), (2, 17, 33, 32, 16, 5, 1),
     (2, 32, 32, 128, 128, 1, 1), (2, 32, 32, 48, 48, 3, 1), (1, 16, 16, 256, 256, 3, 1),
+    # path 6: the 8-channel-chunk form of the 3x3 MF = 32 kernel (what launches of >= 1536 items take)
+    (2, 32, 32, 32, 32, 3, 6), (2, 48, 40, 32, 64, 3, 6), (1, 32, 32, 224, 96, 3, 6), (2, 21, 19, 64, 160, 3, 6),
+    (1, 16, 16, 256, 256, 3, 6), (2, 30, 18, 8, 32, 3, 6),
     (2, 32, 32, 1, 32, 3, 2), (2, 32, 32, 2, 32, 3, 2), (2, 30, 18, 1, 16, 5, 2), (2, 32, 32, 16, 1, 5, 2),
     # single output channel (dD/dx): the 4-pixels-per-thread kernel, ragged tiles, channel tails, both kernel sizes
     (2, 45, 70, 16, 1, 5, 2), (2, 33, 31, 8, 1, 3, 2), (1, 40, 40, 6, 1, 5, 2), (1, 20, 36, 12, 1, 3, 2),
@@ -192,12 +195,14 @@ def test_maxpool(lib):
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("case", [(16, 128, 128, 32, 64, 3), (12, 96, 112, 16, 16, 5), (8, 72, 136, 96, 32, 3)])
+@pytest.mark.parametrize("case", [(16, 128, 128, 32, 64, 3), (12, 96, 112, 16, 16, 5), (8, 72, 136, 96, 32, 3),
+                                  (16, 128, 128, 32, 64, 3, 6), (8, 72, 136, 96, 32, 3, 6)])
 def test_persistent_conv_grid_matches_one_item_per_workgroup(lib, case, monkeypatch):
     """The persistent form of the conv kernel (workgroups looping over items, staging geometry hoisted) must give
     the same bits as the one-item-per-workgroup form, on interior and border tiles (ragged sizes) alike."""
     from dep_gan_im_amd import _lib
-    B, H, W, ci, co, k = case
+    B, H, W, ci, co, k = case[:6]
+    path = case[6] if len(case) > 6 else 1          # 6: the 8-channel-chunk form (four resident workgroups per CU)
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(ci + co + k)
     x = torch.from_numpy(rng.standard_normal((B, H, W, ci)).astype(np.float32)).to(dev)
@@ -207,7 +212,7 @@ def test_persistent_conv_grid_matches_one_item_per_workgroup(lib, case, monkeypa
     for per_cu in ("0", "1", "2"):
         monkeypatch.setenv("DEPGAN_IGEMM_PERSIST", per_cu)      # read by the launcher at every launch
         out = torch.full((B, H, W, co), float("nan"), device=dev)
-        _lib.check(lib.depgan_op_conv2d(P(x), P(w), P(b), P(out), B, H, W, ci, co, k, 1, 1, None))
+        _lib.check(lib.depgan_op_conv2d(P(x), P(w), P(b), P(out), B, H, W, ci, co, k, 1, path, None))
         torch.cuda.synchronize()
         outs.append(out.cpu().numpy())
     np.testing.assert_array_equal(outs[0], outs[1])
