@@ -211,6 +211,10 @@ void zero_ep(Epilogue* e);
 TView view_offset(TView v, long samples);
 TView strided2(TView v, int di, int dj);
 int deconv_bwd_data(depgan_ctx* c, GLayer& L, TView dsrc, int n);
+// forward of a transposed convolution on the fused four-tap kernel (deconv_fwd.hip) where it covers the layer
+bool deconv_fused(const depgan_ctx* c, const GLayer& L, int n);
+int deconv_fwd_launch(depgan_ctx* c, const GLayer& L, TView out, const float* bias, const float* scale,
+                      const float* shift, int relu, int n);
 // column sums of dy over its first B samples, delivered with the weight gradient: out = scale * sum, raw = sum
 struct ColSum {
   int B;

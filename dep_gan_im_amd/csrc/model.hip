@@ -133,6 +133,29 @@ int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
   return dg_conv_direct(KS, a, c->st);
 }
 
+// Forward of a transposed convolution on the fused four-tap kernel (deconv_fwd.hip): fp32 contexts only -- the bf16 /
+// split modes keep their own matrix-pipe kernels through the grouped launch.
+bool deconv_fused(const depgan_ctx* c, const GLayer& L, int n) {
+  if (c->cfg.bf16_mfma || c->cfg.f32_split) return false;
+  return dg_deconv_fwd_supported(n, L.H, L.W, L.Cin, L.Cout, L.in, L.out);
+}
+int deconv_fwd_launch(depgan_ctx* c, const GLayer& L, TView out, const float* bias, const float* scale,
+                      const float* shift, int relu, int n) {
+  DeconvArgs d;
+  memset(&d, 0, sizeof(d));
+  d.in = L.in.p;
+  d.w = L.Wt;
+  d.out = out;
+  d.bias = bias; d.scale = scale; d.shift = shift; d.relu = relu;
+  d.H = L.H; d.W = L.W; d.Cin = L.Cin; d.Cout = L.Cout;
+  char lb[56];
+  snprintf(lb, sizeof(lb), "conv k1 b%d %dx%d %d->%d x4", n, L.H, L.W, L.Cin, L.Cout);
+  const double px = 4.0 * n * L.H * L.W;
+  ProfScope ps(c, 0, 2.0 * n * L.H * L.W * (double)L.Cin * L.Cout * 4, lb,
+               px * L.Cin + 4 * (px * L.Cout + 4.0 * L.Cin * L.Cout));
+  return dg_deconv_fwd(d, n, c->st);
+}
+
 int deconv_bwd_data(depgan_ctx* c, GLayer& L, TView dsrc, int n) {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
@@ -722,6 +745,10 @@ int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u
     } else if (L.kind == G_DECONV) {
       // 2x2 / stride-2 transposed convolution = four 1x1 convolutions of the same input, tap (di, dj) writing the
       // pixel grid (2i+di, 2j+dj): one grouped launch, the input tile is fetched once per XCD
+      if (deconv_fused(c, L, n)) {
+        DGCHECK(deconv_fwd_launch(c, L, L.out, L.b, L.s, L.t, 1, n));
+        continue;
+      }
       ConvArgs a;
       memset(&a, 0, sizeof(a));
       zero_ep(&a.ep);

@@ -198,7 +198,7 @@ static int u_forward_train(depgan_ctx* c, const float* x, const float* z, int n,
       ProfScope ps(c, 2, 0.0);
       DGCHECK(dg_maxpool(c->gl[L.skip_of].out, L.out, n, L.H / 2, L.W / 2, L.Cout, c->st));
     } else if (L.kind == G_DECONV) {
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < 4 && !deconv_fused(c, L, n); ++t) {
         ConvArgs a;
         memset(&a, 0, sizeof(a));
         zero_ep(&a.ep);
@@ -209,6 +209,7 @@ static int u_forward_train(depgan_ctx* c, const float* x, const float* z, int n,
         a.w = L.wpf[t];
         DGCHECK(conv_launch(c, L.pf, a, 1));
       }
+      if (deconv_fused(c, L, n)) DGCHECK(deconv_fwd_launch(c, L, L.raw.view(), L.b, nullptr, nullptr, 0, n));
       DGCHECK(u_bn_act(c, L, 2 * L.H, 2 * L.W, n, 0));
     }
   }
