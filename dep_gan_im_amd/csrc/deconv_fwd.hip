@@ -26,8 +26,33 @@
 #include "common.h"
 #include "deconv_fwd.h"
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 namespace {
+
+// DECONV_STAMPS (tools/micro/deconv_stamps.hip only): s_memtime at five points of a workgroup's tile number stamp_it (0: top,
+// 4 / 5: before / after the tile barrier, 2: after the last MFMA, 3: after the LDS-block writes) and at the top of
+// the next one (1)
+#ifdef DECONV_STAMPS
+#define DSTAMP(k) do { if (it == a.stamp_it) st_t[k] = __builtin_amdgcn_s_memtime(); \
+                       if ((k) == 0 && it == a.stamp_it + 1) st_t[1] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DSTAMP(k) do { } while (0)
+#endif
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The pipeline below decides per
+// MFMA slot which side operations ride in it; with the slot index a constant expression every such test is an
+// `if constexpr` and every register-array index a literal (a `#pragma unroll` loop of this size is over the
+// unroller's budget and leaves the arrays in scratch memory).
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 template <int CIN, int MT>
 struct DCfg {
@@ -35,30 +60,49 @@ struct DCfg {
   static constexpr int ROW4 = 33;               // float4 slots per (q, h) row: 32 pixels + 1 pad
   static constexpr int BUF4 = 2 * NQ * ROW4;    // float4 slots of one staging buffer
   static constexpr int LD4 = CIN / 32;          // float4 loads per thread per tile (32 * CIN / 4 / 256)
-  static constexpr int CP = 36;                 // floats per pixel row of the epilogue block
-  static constexpr size_t LDS_BYTES = (size_t)2 * BUF4 * 16 + (size_t)4 * 32 * CP * 4;
+  static constexpr int CP = 36;                 // floats per pixel row of an epilogue block
+  static constexpr int ES = 32 * CP;            // floats of one [32 pixels][CP] epilogue block
+  static constexpr int NWG = 128 * MT;          // channels of the N axis per workgroup
+  // staging double buffer | per wave MT epilogue blocks | folded bias of the workgroup's channels
+  static constexpr size_t LDS_BYTES = (size_t)2 * BUF4 * 16 + (size_t)4 * MT * ES * 4 + (size_t)NWG * 4;
 };
 
 template <int CIN, int MT>
-__global__ __launch_bounds__(256, 2) void deconv_fwd_kernel(DeconvArgs a) {
+__global__ __launch_bounds__(256, 1) void deconv_fwd_kernel(DeconvArgs a) {
   using C = DCfg<CIN, MT>;
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   f32x4* stage = reinterpret_cast<f32x4*>(smem_raw);                    // [2][2 NQ][33]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  float* es = smem_raw + 2 * C::BUF4 * 4 + wv * (32 * C::CP);           // this wave's [32][CP] block
+  float* es = smem_raw + 2 * C::BUF4 * 4 + wv * (MT * C::ES);           // this wave's MT blocks of [32][CP]
+  float* bt = smem_raw + 2 * C::BUF4 * 4 + 4 * MT * C::ES;              // [NWG] folded bias
   const int r = lane & 31, h = lane >> 5;
   const int nTiles = a.nTiles;
   // channel range of this wave on the N = 4 Cout axis
-  const int n0 = (blockIdx.y * 4 + wv) * (32 * MT);
+  const int nwg0 = blockIdx.y * C::NWG;
+  const int n0 = nwg0 + wv * (32 * MT);
 
-  // ---- weights of the wave's channels, whole K, into registers: wq[m][q] = W[n0 + 32 m + r][8 q + 4 h + 0..3] ----
+  // ---- the affine epilogue is folded into the contraction: (acc + b) s + t = sum (s w) x + (b s + t) ----
+  // the weights are scaled once per workgroup as they enter the registers, the constant term starts the accumulators
+  // (read from LDS straight into them) -- what is left after the MFMAs is the ReLU.
+  for (int cidx = tid; cidx < C::NWG; cidx += 256) {
+    const int co = (nwg0 + cidx) % a.Cout;
+    const float s = a.scale ? a.scale[co] : 1.f;
+    bt[cidx] = (a.bias ? a.bias[co] : 0.f) * s + (a.scale ? a.shift[co] : 0.f);
+  }
+  // wq[m][q] = s[n] W[n = n0 + 32 m + r][8 q + 4 h + 0..3]
   // (N axis = [tap][co], weight tensor (kh, kw, Cout, Cin): row n of the [4 Cout][Cin] matrix is a.w + n * CIN)
   f32x4 wq[MT][C::NQ];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const float* wrow = a.w + (size_t)(n0 + 32 * m + r) * CIN + 4 * h;
+    const int n = n0 + 32 * m + r;
+    const float* wrow = a.w + (size_t)n * CIN + 4 * h;
+    const float s = a.scale ? a.scale[n % a.Cout] : 1.f;
 #pragma unroll
-    for (int q = 0; q < C::NQ; ++q) wq[m][q] = *reinterpret_cast<const f32x4*>(wrow + 8 * q);
+    for (int q = 0; q < C::NQ; ++q) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + 8 * q);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wq[m][q][k] = w4[k] * s;
+    }
   }
 
   // ---- staging: thread t fetches float4 f = t + 256 i of the tile's [32][CIN] block: pixel f / (CIN/4), chunk j ----
@@ -73,116 +117,157 @@ __global__ __launch_bounds__(256, 2) void deconv_fwd_kernel(DeconvArgs a) {
   constexpr int TILE4 = 32 * CIN / 4;
 
   int tile = blockIdx.x;
-  if (tile < nTiles) {
 #pragma unroll
-    for (int i = 0; i < C::LD4; ++i) stage[st_slot[i]] = in4[(size_t)tile * TILE4 + tid + 256 * i];
-  }
+  for (int i = 0; i < C::LD4; ++i) stage[st_slot[i]] = in4[(size_t)tile * TILE4 + tid + 256 * i];
   __syncthreads();
 
-  // epilogue constants of the lane: channel quad c4 of a 32-channel tile, pixel pl0 of an 8-pixel pass
+  // epilogue constants of the lane: channel quad c4 of a 32-channel tile, pixel pl0 of an 8-pixel pass; per channel
+  // tile the (wave-uniform) offset of its tap and first channel
   const int c4 = (lane & 7) * 4, pl0 = lane >> 3;
-  const long lane_off = (long)pl0 * 2 * a.out.sX;
-  int cur = 0;
-  for (; tile < nTiles; tile += gridDim.x) {
-    // next tile's loads first: they fly under the MFMA loop and the epilogue
-    const int nxt = tile + gridDim.x;
-    f32x4 pre[C::LD4];
-    if (nxt < nTiles) {
+  const int lane_off = pl0 * 2 * (int)a.out.sX + c4;
+  long tap_off[MT];
 #pragma unroll
-      for (int i = 0; i < C::LD4; ++i) pre[i] = in4[(size_t)nxt * TILE4 + tid + 256 * i];
-    }
-
-    // ---- contraction: acc[m] (32 channels x 32 pixels) over the whole K ----
-    f32x16 acc[MT];
+  for (int m = 0; m < MT; ++m) {
+    const int n = __builtin_amdgcn_readfirstlane(n0 + 32 * m);
+    const int tap = n / a.Cout, co0 = n - tap * a.Cout;
+    tap_off[m] = (long)(tap >> 1) * a.out.sY + (long)(tap & 1) * a.out.sX + co0;
+  }
+  // folded bias of the wave's channels in the accumulator layout (quad g of channel tile m: channels 8 g + 4 h + 0..3):
+  // the C operand of every tile's first MFMA per channel tile -- starting the accumulators costs no instruction
+  __syncthreads();
+  f32x16 cb[MT];
+  {
+    const f32x4* bt4 = reinterpret_cast<const f32x4*>(bt + wv * (32 * MT)) + h;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int k = 0; k < 16; ++k) acc[m][k] = 0.f;
-    const f32x4* sb = stage + cur * C::BUF4 + h * C::ROW4 + r;
-    f32x4 bq = sb[0];
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = bt4[8 * m + 2 * g];
 #pragma unroll
-    for (int q = 0; q < C::NQ; ++q) {
-      f32x4 bn = bq;
-      if (q + 1 < C::NQ) bn = sb[(2 * (q + 1)) * C::ROW4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[m][q][j], bq[j], acc[m], 0, 0, 0);
-      bq = bn;
-    }
+        for (int k = 0; k < 4; ++k) cb[m][4 * g + k] = b4[k];
+      }
+  }
+  const float lo = a.relu ? 0.f : -__builtin_inff();
 
-    // ---- epilogue ----
-    // pixel rows of the four 8-pixel passes (W % 8 == 0: a pass never crosses an image row)
-    long pass_off[4];
+  // piece p = 4 m + k of a finished tile: the 8 pixels of pass k x the 32 channels of tile m = 8 whole 128-byte lines.
+  // H and W are powers of two (the launcher checks): the pixel decomposition is shifts and masks on the scalar unit,
+  // the offsets are 32-bit float offsets.
+  auto piece_read = [&](int p) __attribute__((always_inline)) {
+    return *reinterpret_cast<const f32x4*>(es + (p >> 2) * C::ES + (8 * (p & 3) + pl0) * C::CP + c4);
+  };
+  auto piece_store = [&](int p, int t_done, f32x4 v) __attribute__((always_inline)) {
+    const unsigned P = (unsigned)t_done * 32u + 8u * (unsigned)(p & 3);
+    const unsigned j0 = P & (unsigned)(a.W - 1), t = P >> a.lgW;
+    const unsigned i0 = t & (unsigned)(a.H - 1), b0 = t >> a.lgH;
+    float* prow = a.out.p + (size_t)(b0 * (unsigned)a.out.sB + i0 * (2u * (unsigned)a.out.sY) +
+                                     j0 * (2u * (unsigned)a.out.sX));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned P = (unsigned)tile * 32u + 8u * k;   // wave-uniform
-      unsigned j0, i0, b0;
-      if (a.lgW >= 0 && a.lgH >= 0) {
-        j0 = P & (a.W - 1);
-        const unsigned t = P >> a.lgW;
-        i0 = t & (a.H - 1);
-        b0 = t >> a.lgH;
-      } else {
-        j0 = P % (unsigned)a.W;
-        const unsigned t = P / (unsigned)a.W;
-        i0 = t % (unsigned)a.H;
-        b0 = t / (unsigned)a.H;
-      }
-      pass_off[k] = (long)b0 * a.out.sB + (long)(2 * i0) * a.out.sY + (long)(2 * j0) * a.out.sX;
-    }
+    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], lo);      // ReLU (or nothing: lo = -inf)
+    *reinterpret_cast<f32x4*>(prow + tap_off[p >> 2] + lane_off) = v;
+  };
+
+  // ---- software pipeline, per wave ----
+  // On this hardware nothing overlaps with a wave's fp32 MFMA stream except what is issued INSIDE it: another wave's
+  // vector, LDS or store instructions do not issue while an older wave of the SIMD streams MFMAs (DESIGN.md section
+  // 4), and instructions bunched between two streams cost their full latency (stamps, tools/micro/deconv_stamps.hip:
+  // 7 070 cycles per tile with the epilogue behind the stream against 4 096 of MFMAs).  So the MFMA stream of tile t
+  // carries, in the gaps between its MFMAs and a handful of issues per gap, everything else:
+  //   gap 0 ..            global loads of tile t + 1 (registers; into LDS near the end of the stream)
+  //   first gap of a K group   the B operand of K group q + BD (16-byte LDS read)
+  //   from gap R0, every SR    LDS-block read of one piece of tile t - 1; ReLU and its store three gaps later
+  //   gap S0 ..           tile t + 1 into the other staging buffer; the tile barrier before the last K group; the
+  //                       first BD K groups of tile t + 1's B operand in the last gaps
+  // and what follows the stream is only the transposing write of the accumulators into the wave's LDS blocks (4 MT
+  // 16-byte writes straight from the accumulator registers), read back piece by piece inside the next stream.
+  // sched_barrier after every MFMA pins this placement.
+  constexpr int G4 = 4 * MT;              // MFMAs per K group
+  constexpr int NM = C::NQ * G4;          // MFMAs per tile and wave
+  constexpr int NW = 4 * MT;              // accumulator quads = pieces per tile and wave
+  constexpr int BD = 4;                   // B-operand reads run this many K groups ahead
+  constexpr int S0 = NM - G4 - C::LD4 - 2;
+  constexpr int R0 = 2;
+  constexpr int SR = (S0 - R0) / NW;
+  static_assert(SR >= 4 && C::NQ > BD, "pipeline slots");
+
+  f32x4 bfirst[BD];
+  int cur = 0, done = -1;           // done: tile whose result sits in the wave's LDS blocks, not yet stored
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int n = __builtin_amdgcn_readfirstlane(n0 + 32 * m);
-      const int tap = n / a.Cout, co0 = n - tap * a.Cout;
-      const long tap_off = (long)(tap >> 1) * a.out.sY + (long)(tap & 1) * a.out.sX + co0 + c4;
-      f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-      if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + co0 + c4);
-      if (a.scale) {
-        sc4 = *reinterpret_cast<const f32x4*>(a.scale + co0 + c4);
-        sh4 = *reinterpret_cast<const f32x4*>(a.shift + co0 + c4);
+  for (int q = 0; q < BD; ++q) bfirst[q] = stage[h * C::ROW4 + r + 2 * q * C::ROW4];
+
+#ifdef DECONV_STAMPS
+  unsigned long long st_t[6] = {0, 0, 0, 0, 0, 0};
+  int it = 0;
+#endif
+  auto body = [&](auto have_c) __attribute__((always_inline)) {
+    constexpr bool HAVE = decltype(have_c)::value;
+    DSTAMP(0);
+    const int nxt = tile + gridDim.x;
+    const int nld = nxt < nTiles ? nxt : tile;   // the last tile re-reads itself: no branch around the loads
+    const f32x4* sb = stage + cur * C::BUF4 + h * C::ROW4 + r;
+    const f32x4* sn = stage + (cur ^ 1) * C::BUF4 + h * C::ROW4 + r;
+    f32x16 acc[MT];
+    f32x4 bq[C::NQ];
+#pragma unroll
+    for (int q = 0; q < BD; ++q) bq[q] = bfirst[q];
+    f32x4 pre[C::LD4];
+    f32x4 pv[2];
+    pv[0] = pv[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    static_for<NM>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int q = i / G4, wi = i % G4, j = wi / MT, m = wi % MT;
+      if constexpr (i < C::LD4) pre[i] = in4[(size_t)nld * TILE4 + tid + 256 * i];
+      if constexpr (wi == 0 && q + BD < C::NQ) bq[q + BD] = sb[2 * (q + BD) * C::ROW4];
+      if constexpr (HAVE && i >= R0 && i < R0 + NW * SR) {
+        constexpr int p = (i - R0) / SR, ph = (i - R0) % SR;
+        if constexpr (ph == 0) pv[p & 1] = piece_read(p);
+        if constexpr (ph == 3) piece_store(p, done, pv[p & 1]);
       }
-      // lane (r, h) holds channels 8 g + 4 h + 0..3 of pixel r in acc[m][4g .. 4g+3]
+      if constexpr (i >= S0 && i < S0 + C::LD4) stage[(cur ^ 1) * C::BUF4 + st_slot[i - S0]] = pre[i - S0];
+      if constexpr (i == NM - G4) {
+        DSTAMP(4);
+        __syncthreads();
+        DSTAMP(5);
+      }
+      if constexpr (i > NM - G4 && i <= NM - G4 + BD) {
+        constexpr int k = i - (NM - G4) - 1;
+        bfirst[k] = sn[2 * k * C::ROW4];
+      }
+      if constexpr (q == 0 && j == 0)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[m][q][j], bq[q][j], cb[m], 0, 0, 0);
+      else
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[m][q][j], bq[q][j], acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    DSTAMP(2);
+    // the finished tile into the wave's LDS blocks: lane (r, h) holds channels 8 g + 4 h + 0..3 of pixel r in
+    // acc[m][4g .. 4g+3].  The same wave writes and reads its blocks; LDS executes a wave's accesses in order.
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 q4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) q4[k] = acc[m][4 * g + k];
-        *reinterpret_cast<f32x4*>(es + r * C::CP + 8 * g + 4 * h) = q4;
+        *reinterpret_cast<f32x4*>(es + m * C::ES + r * C::CP + 8 * g + 4 * h) = q4;
       }
-      // same wave writes and reads the block: LDS executes a wave's accesses in order, the fences keep the compiler
-      // from moving the reads above the writes (and the next tile's writes above these reads)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      f32x4 v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(es + (8 * k + pl0) * C::CP + c4);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = v[k][e] + bias4[e];
-          if (a.scale) x = __fadd_rn(__fmul_rn(x, sc4[e]), sh4[e]);
-          if (a.relu) x = fmaxf(x, 0.f);
-          v[k][e] = x;
-        }
-        *reinterpret_cast<f32x4*>(a.out.p + pass_off[k] + tap_off + lane_off) = v[k];
-      }
-    }
-
-    // ---- next tile into the other staging buffer (its readers finished before the previous barrier) ----
-    if (nxt < nTiles) {
-#pragma unroll
-      for (int i = 0; i < C::LD4; ++i) stage[(cur ^ 1) * C::BUF4 + st_slot[i]] = pre[i];
-    }
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    DSTAMP(3);
+    done = tile;
     cur ^= 1;
-  }
+#ifdef DECONV_STAMPS
+    ++it;
+#endif
+  };
+
+  body(std::false_type{});
+  for (tile += gridDim.x; tile < nTiles; tile += gridDim.x) body(std::true_type{});
+  // the last tile's stores
+#pragma unroll
+  for (int p = 0; p < NW; ++p) piece_store(p, done, piece_read(p));
+#ifdef DECONV_STAMPS
+  if (lane == 0 && a.stamps)
+    for (int k = 0; k < 6; ++k) a.stamps[(blockIdx.x * 4 + wv) * 8 + k] = st_t[k];
+#endif
 }
 
 template <int CIN, int MT>
@@ -236,8 +321,10 @@ bool dg_deconv_fwd_supported(int B, int H, int W, int Cin, int Cout, TView in, T
   if (Cin != 64 && Cin != 96 && Cin != 128) return false;
   if (Cout % 32) return false;
   if ((4 * Cout) % (128 * mt_for(Cin))) return false;
-  if (W % 8 || ((long)B * H * W) % 32) return false;
-  if ((long)B * H * W / 32 > 0x3FFFFFF) return false;
+  // power-of-two image sizes of at least 8 pixels (a pass of 8 pixels never crosses an image row, pixel -> (b, i, j) is
+  // shifts and masks), whole 32-pixel tiles, the output addressable with 32-bit float offsets
+  if (W < 8 || H < 1 || (W & (W - 1)) || (H & (H - 1)) || ((long)B * H * W) % 32) return false;
+  if ((long)B * H * W / 32 > 0x3FFFFFF || (long)B * out.sB > 0x7FFFFFFFL) return false;
   // dense NHWC input (the staging reads it as one flat [pixels][Cin] matrix), 16-byte aligned views
   if (in.sX != Cin || in.sY != (long)W * Cin || in.sB != (long)H * W * Cin) return false;
   if (((uintptr_t)in.p | (uintptr_t)out.p) & 15) return false;

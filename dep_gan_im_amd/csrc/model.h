@@ -9,6 +9,7 @@
 
 #include "../../include/depgan.h"
 #include "common.h"
+#include "deconv_fwd.h"
 #include "noise.h"
 #include "ops.h"
 

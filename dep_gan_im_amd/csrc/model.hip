@@ -1575,6 +1575,19 @@ int depgan_op_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, in
   hipFree(part);
   return rc;
 }
+int depgan_op_deconv2x2(const float* in, const float* w_hwoi, const float* bias, const float* scale,
+                        const float* shift, float* out, int B, int H, int W, int Cin, int Cout, int relu,
+                        void* stream) {
+  if (!in || !w_hwoi || !out || B < 1 || H < 1 || W < 1) { dg_set_error("op_deconv2x2: bad argument"); return DG_ERR_ARG; }
+  DeconvArgs d;
+  memset(&d, 0, sizeof(d));
+  d.in = in;
+  d.w = w_hwoi;
+  d.out = make_view(out, 2 * H, 2 * W, Cout);
+  d.bias = bias; d.scale = scale; d.shift = shift; d.relu = relu;
+  d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout;
+  return dg_deconv_fwd(d, B, (hipStream_t)stream);
+}
 int depgan_op_maxpool(const float* in, float* out, int B, int Ho, int Wo, int C, void* stream) {
   return dg_maxpool(make_view(const_cast<float*>(in), 2 * Ho, 2 * Wo, C), make_view(out, Ho, Wo, C), B, Ho, Wo, C,
                     (hipStream_t)stream);

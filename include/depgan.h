@@ -214,6 +214,14 @@ int depgan_op_conv2d_wgrad(const float* x, const float* dy, float* dw_hwio, int 
 int depgan_op_conv2d_stamps(const float* in, const float* w_hwio, float* out, int B, int H, int W, int Cin, int Cout,
                             int KS, unsigned long long* stamps, int reps, void* hip_stream);
 int depgan_op_maxpool(const float* in, float* out, int B, int Ho, int Wo, int C, void* hip_stream);
+/* Forward of the 2x2 / stride-2 transposed convolution (Conv2DTranspose, GT:308) on the fused four-tap kernel:
+ * out[b][2i+di][2j+dj][co] = act((sum_ci in[b][i][j][ci] w[di][dj][co][ci] + bias[co]) * scale[co] + shift[co]).
+ * w_hwoi is the Keras kernel (2, 2, Cout, Cin); bias / scale+shift may be null; out is dense (B, 2H, 2W, Cout).
+ * Status 3 when the kernel does not cover the shape (Cin in {64, 96, 128}, Cout % 32 == 0, H and W
+ * powers of two, W >= 8, B H W % 32 == 0). */
+int depgan_op_deconv2x2(const float* in, const float* w_hwoi, const float* bias, const float* scale,
+                        const float* shift, float* out, int B, int H, int W, int Cin, int Cout, int relu,
+                        void* hip_stream);
 
 #ifdef __cplusplus
 }

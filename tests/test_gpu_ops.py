@@ -187,6 +187,52 @@ def test_conv_weight_gradient(lib, case):
     assert torch.equal(dw, dw2)
 
 
+DECONV_CASES = [  # B,H,W,Cin,Cout,affine: the three instantiations (64 / 96 / 128 input channels), two channel
+    # halves per pixel tile (Cout = 128), image rows shorter than a 32-pixel tile, H != W
+    (2, 32, 32, 64, 64, True), (1, 16, 64, 96, 96, True), (2, 16, 16, 128, 128, True), (4, 8, 8, 64, 64, False),
+    (1, 4, 32, 64, 128, False), (3, 32, 16, 96, 96, False), (2, 16, 8, 128, 64, True),
+]
+
+
+@pytest.mark.parametrize("case", DECONV_CASES)
+def test_fused_transposed_conv_forward(lib, case):
+    """deconv_fwd.hip (all four taps of the 2x2 / stride-2 Conv2DTranspose in one workgroup, GT:308) against
+    conv_transpose2d in float64, with and without the BN affine + ReLU epilogue."""
+    from dep_gan_im_amd import _lib
+    B, H, W, ci, co, affine = case
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(ci * 131 + co + H)
+    x = rng.standard_normal((B, H, W, ci)).astype(np.float32)
+    w = (rng.standard_normal((2, 2, co, ci)) / np.sqrt(ci)).astype(np.float32)      # Keras layout (kh, kw, out, in)
+    b = rng.standard_normal(co).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, co).astype(np.float32)
+    sh = rng.standard_normal(co).astype(np.float32)
+    xd, wd, bd, scd, shd = [torch.from_numpy(a).to(dev) for a in (x, w, b, sc, sh)]
+    out = torch.full((B, 2 * H, 2 * W, co), float("nan"), device=dev)
+    _lib.check(lib.depgan_op_deconv2x2(P(xd), P(wd), P(bd), P(scd) if affine else None, P(shd) if affine else None,
+                                       P(out), B, H, W, ci, co, 1 if affine else 0, None))
+    torch.cuda.synchronize()
+    # torch: weight (in, out, kh, kw)
+    y = F.conv_transpose2d(torch.from_numpy(x).permute(0, 3, 1, 2).double(),
+                           torch.from_numpy(w).permute(3, 2, 0, 1).double(), torch.from_numpy(b).double(), stride=2)
+    if affine:
+        y = torch.relu(y * torch.from_numpy(sc).double()[None, :, None, None] +
+                       torch.from_numpy(sh).double()[None, :, None, None])
+    assert rel(out.cpu().numpy(), y.permute(0, 2, 3, 1).numpy()) < TOL
+
+
+def test_fused_transposed_conv_refuses_what_it_does_not_cover(lib):
+    dev = torch.device("cuda:0")
+    x = torch.zeros(1, 8, 8, 48, device=dev)
+    w = torch.zeros(2, 2, 48, 48, device=dev)
+    out = torch.zeros(1, 16, 16, 48, device=dev)
+    assert lib.depgan_op_deconv2x2(P(x), P(w), None, None, None, P(out), 1, 8, 8, 48, 48, 0, None) == 3
+    x = torch.zeros(1, 12, 8, 64, device=dev)                      # image height not a power of two
+    w = torch.zeros(2, 2, 64, 64, device=dev)
+    out = torch.zeros(1, 24, 16, 64, device=dev)
+    assert lib.depgan_op_deconv2x2(P(x), P(w), None, None, None, P(out), 1, 12, 8, 64, 64, 0, None) == 3
+
+
 def test_maxpool(lib):
     from dep_gan_im_amd import _lib
     dev = torch.device("cuda:0")
