@@ -16,7 +16,7 @@ EXPORTS = [
     "depgan_d_forward", "depgan_critic_grads", "depgan_critic_step", "depgan_g_eval", "depgan_g_grads",
     "depgan_g_step", "depgan_apply_adam", "depgan_last_sums", "depgan_profile_enable", "depgan_profile_read",
     "depgan_profile_reset", "depgan_profile_dump", "depgan_op_conv2d", "depgan_op_conv2d_bwd_data", "depgan_op_conv2d_wgrad",
-    "depgan_op_maxpool", "depgan_op_deconv2x2", "depgan_op_conv2d_stamps", "depgan_uresnet_grads", "depgan_uresnet_step",
+    "depgan_op_maxpool", "depgan_op_deconv2x2", "depgan_op_deconv2x2_wgrad", "depgan_op_conv2d_stamps", "depgan_uresnet_grads", "depgan_uresnet_step",
     "depgan_uresnet_eval", "depgan_profile_read_bytes", "depgan_g_eval_multi", "depgan_eval_accumulate", "depgan_eval_counts",
     "depgan_data_prep_scratch_floats", "depgan_data_prep_subject", "depgan_abi_version", "depgan_config_size",
     "depgan_set_allreduce", "depgan_get_adam_step", "depgan_set_adam_step", "depgan_gen_iteration", "depgan_eval_divide",
@@ -127,6 +127,7 @@ def load():
     lib.depgan_data_prep_subject.argtypes = [vp] * 7 + [C.c_int] * 4 + [vp] * 4
     lib.depgan_op_maxpool.argtypes = [vp, vp] + [C.c_int] * 4 + [vp]
     lib.depgan_op_deconv2x2.argtypes = [vp] * 6 + [C.c_int] * 6 + [vp]
+    lib.depgan_op_deconv2x2_wgrad.argtypes = [vp] * 4 + [C.c_int] * 5 + [vp]
     lib.depgan_op_conv2d_stamps.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, vp]
     lib.depgan_uresnet_grads.argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint, fp]
     lib.depgan_uresnet_step.argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint, fp]

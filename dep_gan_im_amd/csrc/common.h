@@ -201,6 +201,10 @@ int dg_wgrad(int KS, const WgradArgs& a, int* nchunks, hipStream_t st);
 int dg_wgrad_finish(const float* part, int nchunks, int ntaps, int Cin, int Cout, const float* scale, float* out,
                     float* raw, int accumulate, int oi, const float* colpart, int colC, const float* colscale,
                     float* colout, float* colraw, hipStream_t st);
+// ... with a number of partial column rows that differs from the number of slabs (deconv_wgrad.hip: one row per tap)
+int dg_wgrad_finish_rows(const float* part, int nchunks, int ntaps, int Cin, int Cout, const float* scale, float* out,
+                         float* raw, int accumulate, int oi, const float* colpart, int colrows, int colC,
+                         const float* colscale, float* colout, float* colraw, hipStream_t st);
 int dg_wgrad_reduce(const float* part, int nchunks, int ntaps, int Cin, int Cout, const float* scale, float* out,
                     float* raw, int accumulate, int oi, hipStream_t st);
 

@@ -67,7 +67,8 @@ struct DCfg {
   static constexpr size_t LDS_BYTES = (size_t)2 * BUF4 * 16 + (size_t)4 * MT * ES * 4 + (size_t)NWG * 4;
 };
 
-template <int CIN, int MT>
+// WIDE: the image rows are at least 32 pixels long, i.e. a 32-pixel tile lies in one row
+template <int CIN, int MT, bool WIDE>
 __global__ __launch_bounds__(256, 1) void deconv_fwd_kernel(DeconvArgs a) {
   using C = DCfg<CIN, MT>;
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
@@ -155,17 +156,24 @@ __global__ __launch_bounds__(256, 1) void deconv_fwd_kernel(DeconvArgs a) {
   auto piece_read = [&](int p) __attribute__((always_inline)) {
     return *reinterpret_cast<const f32x4*>(es + (p >> 2) * C::ES + (8 * (p & 3) + pl0) * C::CP + c4);
   };
-  auto piece_store = [&](int p, int t_done, f32x4 v) __attribute__((always_inline)) {
-    const unsigned P = (unsigned)t_done * 32u + 8u * (unsigned)(p & 3);
+  // float offset of output pixel (2 i, 2 j) for the first pixel of pass k of tile t_done: H and W are powers of two
+  // (the launcher checks), so the pixel decomposition is shifts and masks on the scalar unit; 32-bit offsets
+  auto pass_base = [&](int t_done, int k) __attribute__((always_inline)) {
+    const unsigned P = (unsigned)t_done * 32u + 8u * (unsigned)k;
     const unsigned j0 = P & (unsigned)(a.W - 1), t = P >> a.lgW;
     const unsigned i0 = t & (unsigned)(a.H - 1), b0 = t >> a.lgH;
-    float* prow = a.out.p + (size_t)(b0 * (unsigned)a.out.sB + i0 * (2u * (unsigned)a.out.sY) +
-                                     j0 * (2u * (unsigned)a.out.sX));
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], lo);      // ReLU (or nothing: lo = -inf)
-    *reinterpret_cast<f32x4*>(prow + tap_off[p >> 2] + lane_off) = v;
+    return b0 * (unsigned)a.out.sB + i0 * (2u * (unsigned)a.out.sY) + j0 * (2u * (unsigned)a.out.sX);
   };
-
+  auto piece_store = [&](int p, const unsigned (&base)[4], f32x4 v) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // ReLU (or nothing: lo = -inf); one v_max_f32 -- fmaxf() costs a second one that quiets a signalling NaN first
+      float o;
+      asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(v[k]), "v"(lo));
+      v[k] = o;
+    }
+    *reinterpret_cast<f32x4*>(a.out.p + (size_t)base[p & 3] + tap_off[p >> 2] + lane_off) = v;
+  };
   // ---- software pipeline, per wave ----
   // On this hardware nothing overlaps with a wave's fp32 MFMA stream except what is issued INSIDE it: another wave's
   // vector, LDS or store instructions do not issue while an older wave of the SIMD streams MFMAs (DESIGN.md section
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void deconv_fwd_kernel(DeconvArgs a) {
   constexpr int NW = 4 * MT;              // accumulator quads = pieces per tile and wave
   constexpr int BD = 4;                   // B-operand reads run this many K groups ahead
   constexpr int S0 = NM - G4 - C::LD4 - 2;
-  constexpr int R0 = 2;
+  constexpr int R0 = 4;
   constexpr int SR = (S0 - R0) / NW;
   static_assert(SR >= 4 && C::NQ > BD, "pipeline slots");
 
@@ -212,15 +220,21 @@ __global__ __launch_bounds__(256, 1) void deconv_fwd_kernel(DeconvArgs a) {
     f32x4 pre[C::LD4];
     f32x4 pv[2];
     pv[0] = pv[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned base[4] = {0u, 0u, 0u, 0u};        // pass origins of the finished tile (scalar registers)
     static_for<NM>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       constexpr int q = i / G4, wi = i % G4, j = wi / MT, m = wi % MT;
       if constexpr (i < C::LD4) pre[i] = in4[(size_t)nld * TILE4 + tid + 256 * i];
       if constexpr (wi == 0 && q + BD < C::NQ) bq[q + BD] = sb[2 * (q + BD) * C::ROW4];
+      if constexpr (HAVE && i < 4) {
+        if constexpr (i == 0) base[0] = pass_base(done, 0);
+        else if constexpr (WIDE) base[i] = base[0] + (unsigned)(16 * i) * (unsigned)a.out.sX;   // passes 8 pixels apart
+        else base[i] = pass_base(done, i);
+      }
       if constexpr (HAVE && i >= R0 && i < R0 + NW * SR) {
         constexpr int p = (i - R0) / SR, ph = (i - R0) % SR;
         if constexpr (ph == 0) pv[p & 1] = piece_read(p);
-        if constexpr (ph == 3) piece_store(p, done, pv[p & 1]);
+        if constexpr (ph == 3) piece_store(p, base, pv[p & 1]);
       }
       if constexpr (i >= S0 && i < S0 + C::LD4) stage[(cur ^ 1) * C::BUF4 + st_slot[i - S0]] = pre[i - S0];
       if constexpr (i == NM - G4) {
@@ -262,23 +276,28 @@ __global__ __launch_bounds__(256, 1) void deconv_fwd_kernel(DeconvArgs a) {
   body(std::false_type{});
   for (tile += gridDim.x; tile < nTiles; tile += gridDim.x) body(std::true_type{});
   // the last tile's stores
+  {
+    unsigned base[4];
 #pragma unroll
-  for (int p = 0; p < NW; ++p) piece_store(p, done, piece_read(p));
+    for (int k = 0; k < 4; ++k) base[k] = pass_base(done, k);
+#pragma unroll
+    for (int p = 0; p < NW; ++p) piece_store(p, base, piece_read(p));
+  }
 #ifdef DECONV_STAMPS
   if (lane == 0 && a.stamps)
     for (int k = 0; k < 6; ++k) a.stamps[(blockIdx.x * 4 + wv) * 8 + k] = st_t[k];
 #endif
 }
 
-template <int CIN, int MT>
-int launch(const DeconvArgs& a, int ny, hipStream_t st) {
+template <int CIN, int MT, bool WIDE>
+int launch_w(const DeconvArgs& a, int ny, hipStream_t st) {
   using C = DCfg<CIN, MT>;
   static int per_cu = 0;
   if (!per_cu) {
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv_fwd_kernel<CIN, MT>),
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv_fwd_kernel<CIN, MT, WIDE>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     int occ = 0;
-    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, deconv_fwd_kernel<CIN, MT>, 256, C::LDS_BYTES));
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, deconv_fwd_kernel<CIN, MT, WIDE>, 256, C::LDS_BYTES));
     if (occ < 1) occ = 1;
     if (const char* e = getenv("DEPGAN_DECONV_PER_CU")) {
       const int v = atoi(e);
@@ -300,9 +319,14 @@ int launch(const DeconvArgs& a, int ny, hipStream_t st) {
   int gx = cus * per_cu / ny;
   if (gx > a.nTiles) gx = a.nTiles;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL((deconv_fwd_kernel<CIN, MT>), dim3(gx, ny), dim3(256), C::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((deconv_fwd_kernel<CIN, MT, WIDE>), dim3(gx, ny), dim3(256), C::LDS_BYTES, st, a);
   HIPCHECK(hipGetLastError());
   return DG_OK;
+}
+
+template <int CIN, int MT>
+int launch(const DeconvArgs& a, int ny, hipStream_t st) {
+  return a.W >= 32 ? launch_w<CIN, MT, true>(a, ny, st) : launch_w<CIN, MT, false>(a, ny, st);
 }
 
 int mt_for(int Cin) { return Cin == 96 ? 3 : 2; }

@@ -212,6 +212,9 @@ void zero_ep(Epilogue* e);
 TView view_offset(TView v, long samples);
 TView strided2(TView v, int di, int dj);
 int deconv_bwd_data(depgan_ctx* c, GLayer& L, TView dsrc, int n);
+// weight gradient (four taps) + column sums of the upstream gradient of a transposed convolution
+int deconv_wgrad_all(depgan_ctx* c, const GLayer& L, TView dsrc, int n, const float* scale, float* raw,
+                     const float* colscale, float* colout, float* colraw);
 // forward of a transposed convolution on the fused four-tap kernel (deconv_fwd.hip) where it covers the layer
 bool deconv_fused(const depgan_ctx* c, const GLayer& L, int n);
 int deconv_fwd_launch(depgan_ctx* c, const GLayer& L, TView out, const float* bias, const float* scale,

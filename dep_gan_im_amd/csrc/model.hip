@@ -156,6 +156,45 @@ int deconv_fwd_launch(depgan_ctx* c, const GLayer& L, TView out, const float* bi
   return dg_deconv_fwd(d, n, c->st);
 }
 
+// Weight gradient of a transposed convolution (all four taps) and the column sums of its upstream gradient:
+// dW = scale . sum, raw (optional) = the unscaled sum, db = colscale . colsum, draw_col (optional) = colsum.
+// One fused launch + one reduction where deconv_wgrad.hip covers the layer, else the column-sum pass and four
+// per-tap launches of the general kernel.
+int deconv_wgrad_all(depgan_ctx* c, const GLayer& L, TView dsrc, int n, const float* scale, float* raw,
+                     const float* colscale, float* colout, float* colraw) {
+  if (!c->cfg.bf16_mfma && !c->cfg.f32_split &&
+      dg_deconv_wgrad_supported(n, L.H, L.W, L.Cin, L.Cout, L.in, dsrc) &&
+      dg_deconv_wgrad_part_floats(n, L.H, L.W, L.Cin, L.Cout) <= c->partFloats) {
+    DeconvWgradArgs d;
+    memset(&d, 0, sizeof(d));
+    d.in = L.in.p;
+    d.dout = dsrc;
+    d.part = c->part;
+    d.colpart = c->scratch;
+    d.H = L.H; d.W = L.W; d.Cin = L.Cin; d.Cout = L.Cout;
+    int nch = 0;
+    {
+      char lb[56];
+      snprintf(lb, sizeof(lb), "wgrad k1 b%d %dx%d %d->%d x4", n, L.H, L.W, L.Cin, L.Cout);
+      ProfScope ps(c, 1, 2.0 * n * L.H * L.W * (double)L.Cin * L.Cout * 4, lb);
+      DGCHECK(dg_deconv_wgrad(d, n, &nch, c->st));
+    }
+    ProfScope ps(c, 2, 0.0, "slab reduce");
+    return dg_wgrad_finish_rows(c->part, nch, 4, L.Cin, L.Cout, scale, L.dW, raw, 0, 1, c->scratch, 4 * nch, L.Cout,
+                                colscale, colout, colraw, c->st);
+  }
+  {
+    ProfScope ps(c, 2, 0.0, "colsum");
+    DGCHECK(dg_colsum(dsrc, n, 2 * L.H, 2 * L.W, L.Cout, colscale, colout, colraw, 0, c->scratch, c->st));
+  }
+  for (int t = 0; t < 4; ++t) {
+    const size_t o = (size_t)t * L.Cout * L.Cin;
+    DGCHECK(wgrad_full(c, 1, L.in, strided2(dsrc, t / 2, t % 2), n, L.H, L.W, L.Cin, L.Cout, scale, L.dW + o,
+                       raw ? raw + o : nullptr, 0, 1));
+  }
+  return DG_OK;
+}
+
 int deconv_bwd_data(depgan_ctx* c, GLayer& L, TView dsrc, int n) {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
@@ -821,16 +860,7 @@ int g_backward(depgan_ctx* c, const float* x, const float* z, int n) {
       DGCHECK(dg_unpool_mask(L.pool_dsrc, c->gl[L.skip_of].out, L.pool_skipgrad, L.pool_dst, n, L.H / 2, L.W / 2,
                              L.Cout, c->st));
     } else if (L.kind == G_DECONV) {
-      const int Ho = 2 * L.H, Wo = 2 * L.W;
-      {
-        ProfScope ps(c, 2, 0.0, "colsum");
-        DGCHECK(dg_colsum(L.dout, n, Ho, Wo, L.Cout, L.s, L.db, L.dbeta, 0, c->scratch, c->st));
-      }
-      for (int t = 0; t < 4; ++t) {
-        const size_t o = (size_t)t * L.Cout * L.Cin;
-        DGCHECK(wgrad_full(c, 1, L.in, strided2(L.dout, t / 2, t % 2), n, L.H, L.W, L.Cin, L.Cout, L.s, L.dW + o,
-                           c->raw + o, 0, 1));
-      }
+      DGCHECK(deconv_wgrad_all(c, L, L.dout, n, L.s, c->raw, L.s, L.db, L.dbeta));
       {
         ProfScope ps(c, 2, 0.0, "bn gamma grad");
         DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 4 * L.Cin, L.Cout, 1, L.Cin, L.b, L.mean, L.rstd, L.dbeta, L.dgamma,
@@ -1186,6 +1216,10 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
                          : dg_wgrad_small_part_floats(3, B, L.H, L.W, L.Cin, L.Cout);
       else if (L.kind == G_DECONV || (L.kind == G_HEAD && c->train_bn))
         f = dg_wgrad_part_floats(1, B, L.H, L.W, L.Cin, L.Cout);
+      if (L.kind == G_DECONV && dg_deconv_wgrad_supported(B, L.H, L.W, L.Cin, L.Cout, L.in, L.dout)) {
+        const size_t f4 = dg_deconv_wgrad_part_floats(B, L.H, L.W, L.Cin, L.Cout);   // four taps in one slab
+        if (f4 > f) f = f4;
+      }
       if (f > mx) mx = f;
     }
     for (size_t l = 0; l < c->dl.size(); ++l) {
@@ -1587,6 +1621,39 @@ int depgan_op_deconv2x2(const float* in, const float* w_hwoi, const float* bias,
   d.bias = bias; d.scale = scale; d.shift = shift; d.relu = relu;
   d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout;
   return dg_deconv_fwd(d, B, (hipStream_t)stream);
+}
+int depgan_op_deconv2x2_wgrad(const float* in, const float* dout, float* dw_hwoi, float* colsum, int B, int H, int W,
+                              int Cin, int Cout, void* stream) {
+  if (!in || !dout || !dw_hwoi || B < 1 || H < 1 || W < 1) { dg_set_error("op_deconv2x2_wgrad: bad argument"); return DG_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  DeconvWgradArgs d;
+  memset(&d, 0, sizeof(d));
+  d.in = in;
+  d.dout = make_view(const_cast<float*>(dout), 2 * H, 2 * W, Cout);
+  d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout;
+  if (!dg_deconv_wgrad_supported(B, H, W, Cin, Cout, make_view(const_cast<float*>(in), H, W, Cin), d.dout)) {
+    dg_set_error("op_deconv2x2_wgrad: shape %dx%dx%d %d->%d not covered by the fused kernel", B, H, W, Cin, Cout);
+    return DG_ERR_UNSUPPORTED;
+  }
+  const size_t pf = dg_deconv_wgrad_part_floats(B, H, W, Cin, Cout);
+  float *part = nullptr, *col = nullptr;
+  HIPCHECK(hipMalloc((void**)&part, pf * sizeof(float)));
+  if (hipMalloc((void**)&col, (pf / ((size_t)Cin * Cout)) * Cout * sizeof(float)) != hipSuccess) {
+    hipFree(part);
+    dg_set_error("op_deconv2x2_wgrad: out of memory");
+    return DG_ERR_HIP;
+  }
+  d.part = part;
+  d.colpart = colsum ? col : nullptr;
+  int nch = 0;
+  int rc = dg_deconv_wgrad(d, B, &nch, st);
+  if (rc == DG_OK)
+    rc = dg_wgrad_finish_rows(part, nch, 4, Cin, Cout, nullptr, dw_hwoi, nullptr, 0, 1, colsum ? col : nullptr, 4 * nch,
+                              Cout, nullptr, colsum, nullptr, st);
+  hipStreamSynchronize(st);
+  hipFree(part);
+  hipFree(col);
+  return rc;
 }
 int depgan_op_maxpool(const float* in, float* out, int B, int Ho, int Wo, int C, void* stream) {
   return dg_maxpool(make_view(const_cast<float*>(in), 2 * Ho, 2 * Wo, C), make_view(out, Ho, Wo, C), B, Ho, Wo, C,

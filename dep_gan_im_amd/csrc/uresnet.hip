@@ -306,15 +306,7 @@ static int u_backward(depgan_ctx* c, const float* x, const float* z, int n) {
       const int Ho = 2 * L.H, Wo = 2 * L.W;
       TView draw;
       DGCHECK(u_bn_bwd(c, L, L.dout, Ho, Wo, n, 1.0f, &draw));
-      {
-        ProfScope ps(c, 2, 0.0);
-        DGCHECK(dg_colsum(draw, n, Ho, Wo, L.Cout, nullptr, L.db, nullptr, 0, c->scratch, c->st));
-      }
-      for (int t = 0; t < 4; ++t) {
-        const size_t o = (size_t)t * L.Cout * L.Cin;
-        DGCHECK(wgrad_full(c, 1, L.in, strided2(draw, t / 2, t % 2), n, L.H, L.W, L.Cin, L.Cout, nullptr, L.dW + o,
-                           nullptr, 0, 1));
-      }
+      DGCHECK(deconv_wgrad_all(c, L, draw, n, nullptr, nullptr, nullptr, L.db, nullptr));
       DGCHECK(deconv_bwd_data(c, L, draw, n));
     }
   }

@@ -503,9 +503,16 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 int dg_wgrad_finish(const float* part, int nchunks, int ntaps, int Cin, int Cout, const float* scale, float* out,
                     float* raw, int accumulate, int oi, const float* colpart, int colC, const float* colscale,
                     float* colout, float* colraw, hipStream_t st) {
+  return dg_wgrad_finish_rows(part, nchunks, ntaps, Cin, Cout, scale, out, raw, accumulate, oi, colpart, nchunks, colC,
+                              colscale, colout, colraw, st);
+}
+
+int dg_wgrad_finish_rows(const float* part, int nchunks, int ntaps, int Cin, int Cout, const float* scale, float* out,
+                         float* raw, int accumulate, int oi, const float* colpart, int colrows, int colC,
+                         const float* colscale, float* colout, float* colraw, hipStream_t st) {
   const size_t n = (size_t)ntaps * Cin * Cout;
   const unsigned nbr = (unsigned)((n + 63) / 64);
-  ColFin cf = {colpart, colscale, colout, colraw, nchunks, colC};
+  ColFin cf = {colpart, colscale, colout, colraw, colrows, colC};
   const unsigned ncol = colpart ? (unsigned)colC : 0u;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(nbr + ncol), dim3(256), 0, st, part, nchunks, ntaps, Cin, Cout, scale, out,
                      raw, accumulate, oi, nbr, cf);

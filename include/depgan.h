@@ -223,6 +223,12 @@ int depgan_op_deconv2x2(const float* in, const float* w_hwoi, const float* bias,
                         const float* shift, float* out, int B, int H, int W, int Cin, int Cout, int relu,
                         void* hip_stream);
 
+/* Weight gradient of the same layer on the fused kernel (four taps + the column sums of dout in one launch):
+ * dw_hwoi[di][dj][co][ci] = sum_p dout[b][2i+di][2j+dj][co] in[b][i][j][ci]; colsum[co] (optional) = sum of dout over
+ * all output pixels.  Status 3 when not covered (Cin = Cout in {64, 96, 128}, H and W powers of two). */
+int depgan_op_deconv2x2_wgrad(const float* in, const float* dout, float* dw_hwoi, float* colsum, int B, int H, int W,
+                              int Cin, int Cout, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -221,6 +221,29 @@ def test_fused_transposed_conv_forward(lib, case):
     assert rel(out.cpu().numpy(), y.permute(0, 2, 3, 1).numpy()) < TOL
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64), (1, 16, 64, 96, 96), (2, 16, 16, 128, 128), (4, 8, 8, 64, 64),
+                                  (32, 16, 16, 96, 96)])
+def test_fused_transposed_conv_weight_gradient(lib, case):
+    """deconv_wgrad.hip (four taps + the column sums of the upstream gradient in one launch, no LDS) against autograd
+    of conv_transpose2d in float64."""
+    from dep_gan_im_amd import _lib
+    B, H, W, ci, co = case
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(ci * 7 + B + H)
+    x = rng.standard_normal((B, H, W, ci)).astype(np.float32)
+    dy = rng.standard_normal((B, 2 * H, 2 * W, co)).astype(np.float32)
+    xd, dyd = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+    dw = torch.full((2, 2, co, ci), float("nan"), device=dev)
+    cs = torch.full((co,), float("nan"), device=dev)
+    _lib.check(lib.depgan_op_deconv2x2_wgrad(P(xd), P(dyd), P(dw), P(cs), B, H, W, ci, co, None))
+    torch.cuda.synchronize()
+    wt = torch.zeros(ci, co, 2, 2, dtype=torch.float64, requires_grad=True)
+    y = F.conv_transpose2d(torch.from_numpy(x).permute(0, 3, 1, 2).double(), wt, stride=2)
+    (gw,) = torch.autograd.grad(y, wt, torch.from_numpy(dy).permute(0, 3, 1, 2).double())
+    assert rel(dw.cpu().numpy(), gw.permute(2, 3, 1, 0).numpy()) < TOL          # (in, out, kh, kw) -> (kh, kw, out, in)
+    assert rel(cs.cpu().numpy(), dy.astype(np.float64).sum(axis=(0, 1, 2))) < TOL
+
+
 def test_fused_transposed_conv_refuses_what_it_does_not_cover(lib):
     dev = torch.device("cuda:0")
     x = torch.zeros(1, 8, 8, 48, device=dev)

@@ -135,7 +135,7 @@ def _trajectory(which, seed):
     pick = lambda t: ({"G": t.optG, "D_y2": t.optD_y2, "D_dem": t.optD_dem}[which],     # noqa: E731
                       {"G": t._PG, "D_y2": t._PDy2, "D_dem": t._PDdem}[which])
     (opt, Wref), (opt32, W32) = pick(ref), pick(r32)
-    G_list, out_err, out_err32 = [], 0.0, 0.0
+    G_list, out_err, out_err32, out_first = [], 0.0, 0.0, 0.0
     for t in range(3):
         s = slice(t * B, (t + 1) * B)
         if which == "G":
@@ -144,6 +144,8 @@ def _trajectory(which, seed):
             args, name = [y2[s], x[s], z[s], ep[s]], ("netD_y2_train" if which == "D_y2" else "netD_dem_train")
         got, want, w32 = getattr(tr, name)(args), getattr(ref, name)(args), getattr(r32, name)(args)
         out_err, out_err32 = max(out_err, srel(got, want)), max(out_err32, srel(w32, want))
+        if t == 0:
+            out_first = out_err        # same weights on both sides: forward parity alone
         G_list.append({k: np.asarray(v, np.float64) for k, v in opt.m.items()})       # beta1 = 0: m is the gradient
     assert tr.engine.adam_step(which) == 3
     m, v = tr.engine.get_adam_state(which)
@@ -151,7 +153,7 @@ def _trajectory(which, seed):
     W = tr.engine.get_weights(which)
     Wt = {k: W[k] for k in names}
     l2, worst = _masked_weight_check(Wt, P0, {k: Wref[k] for k in names}, G_list, lr, "%s seed %d" % (which, seed))
-    res = dict(out=out_err, out32=out_err32,
+    res = dict(out=out_err, out32=out_err32, out_first=out_first,
                v=max(rel(v[k], opt.v[k]) for k in names), m=max(rel(m[k], opt.m[k]) for k in names),
                v32=max(rel(opt32.v[k], opt.v[k]) for k in names), m32=max(rel(opt32.m[k], opt.m[k]) for k in names),
                l2=l2, worst=worst, flips=max(float(np.abs(W[k] - Wref[k]).max()) for k in names) / lr)
@@ -171,8 +173,11 @@ def test_three_step_trajectory_vs_fp64_oracle(lib, which):
     best seed must be tight."""
     runs = [_trajectory(which, seed) for seed in (131, 149, 151)]
     for r in runs:
-        # three Adam steps move a weight by at most 3 lr on either side; outputs of steps 2-3 see the moved weights
-        assert r["out"] < 3e-2 and r["flips"] <= 2.0 * 3 * 1.05 and r["l2"] < 0.5, r
+        # the first step's outputs are computed from identical weights: forward parity, kinks or not.  Three Adam steps
+        # move a weight by at most 3 lr on either side, whatever the size of its gradient (Adam normalises it), so one
+        # kink event in step 1 re-signs the updates of every weight whose gradient was rounding-sized and the outputs
+        # of steps 2-3 see that: they are only held to the same order of magnitude.
+        assert r["out_first"] < 1e-3 and r["out"] < 0.3 and r["flips"] <= 2.0 * 3 * 1.05 and r["l2"] < 0.5, r
     best = min(runs, key=lambda r: r["m"])
     if which != "G":
         assert best["out"] < 1e-3 and best["m"] < 2e-3 and best["v"] < 2e-3, best
