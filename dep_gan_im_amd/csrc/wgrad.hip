@@ -444,19 +444,23 @@ struct ColFin {
   float *out, *raw;
   int nb, C;
 };
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ in, int nin, int ntaps, int Cin,
-                                                          int Cout, const float* __restrict__ scale,
-                                                          float* __restrict__ out, float* __restrict__ raw,
-                                                          int accumulate, int oi, unsigned nbr, ColFin cf) {
-  __shared__ float sh[256];
+// SL: slices of the slab axis summed side by side (64 SL threads per workgroup).  A small weight tensor has few
+// 64-element groups (144 for 32 -> 32 3x3) against hundreds of slabs: with 4 slices every thread walks 128 slabs one
+// load after the other and the launch is latency (11 us for 19 MB); 16 slices put four times the loads in flight.
+template <int SL>
+__global__ __launch_bounds__(64 * SL) void slab_reduce_kernel(const float* __restrict__ in, int nin, int ntaps, int Cin,
+                                                              int Cout, const float* __restrict__ scale,
+                                                              float* __restrict__ out, float* __restrict__ raw,
+                                                              int accumulate, int oi, unsigned nbr, ColFin cf) {
+  __shared__ float sh[64 * SL];
   if (blockIdx.x >= nbr) {
     // column-sum finish: one channel per block
     const int c = (int)(blockIdx.x - nbr);
     float s = 0.f;
-    for (int b = threadIdx.x; b < cf.nb; b += 256) s += cf.part[(size_t)b * cf.C + c];
+    for (int b = threadIdx.x; b < cf.nb; b += 64 * SL) s += cf.part[(size_t)b * cf.C + c];
     sh[threadIdx.x] = s;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 32 * SL; o > 0; o >>= 1) {
       if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
       __syncthreads();
     }
@@ -470,8 +474,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   const size_t n = (size_t)ntaps * Cin * Cout;
   const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const size_t i = (size_t)blockIdx.x * 64 + el;
-  const int per = (nin + 3) >> 2;
-  const int c0 = sl * per, c1 = min(c0 + per, nin);
+  const int per = (nin + SL - 1) / SL;
+  const int c0 = min(sl * per, nin), c1 = min(c0 + per, nin);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n) {
     int c = c0;
@@ -486,7 +490,9 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (sl == 0 && i < n) {
-    const float s = (sh[el] + sh[64 + el]) + (sh[128 + el] + sh[192 + el]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < SL; k += 4) s += (sh[64 * k + el] + sh[64 * (k + 1) + el]) + (sh[64 * (k + 2) + el] + sh[64 * (k + 3) + el]);
     const int co = (int)(i % Cout);
     const int ci = (int)((i / Cout) % Cin);
     const int tap = (int)(i / ((size_t)Cout * Cin));
@@ -514,8 +520,14 @@ int dg_wgrad_finish_rows(const float* part, int nchunks, int ntaps, int Cin, int
   const unsigned nbr = (unsigned)((n + 63) / 64);
   ColFin cf = {colpart, colscale, colout, colraw, colrows, colC};
   const unsigned ncol = colpart ? (unsigned)colC : 0u;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(nbr + ncol), dim3(256), 0, st, part, nchunks, ntaps, Cin, Cout, scale, out,
-                     raw, accumulate, oi, nbr, cf);
+  // the slice count is a function of the layer alone (its size and slab count), never of the data: the summation
+  // order of a given layer is fixed
+  if (nbr < 2048 && nchunks >= 64)
+    hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3(nbr + ncol), dim3(1024), 0, st, part, nchunks, ntaps, Cin, Cout,
+                       scale, out, raw, accumulate, oi, nbr, cf);
+  else
+    hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3(nbr + ncol), dim3(256), 0, st, part, nchunks, ntaps, Cin, Cout, scale,
+                       out, raw, accumulate, oi, nbr, cf);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }
