@@ -511,7 +511,8 @@ def main():
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; "
                                 "%s)" % traffic_src,
                 "algorithmic_bytes_per_launch": round(conv_bytes / max(conv_n, 1)),
-                "kernel": "igemm_conv_kernel (all shapes: fwd / bwd-data / GP u-forward)",
+                "kernel": "igemm_conv_kernel (all shapes: fwd / bwd-data / GP u-forward) + the 3 deconv_fwd_kernel "
+                          "launches of the generator forward (the convolution class; `traffic` is the igemm kernels')",
                 "avg_launch_us": round(conv_ms / max(conv_n, 1) * 1e3, 2), "launches_per_step": conv_n // 2,
                 "wgrad": {"achieved": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2) if wg_ms > 0 else 0.0,
                           "ms_per_step": round(wg_ms / 2, 3)},

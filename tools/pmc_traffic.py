@@ -49,7 +49,7 @@ def main():
         wr = 1024.0 * sw / nw if nw else None
         rows[name] = {"launches": max(nf, nw), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                       "hbm_bytes_per_launch": (rd or 0.0) + (wr or 0.0)}
-    cls = [v for k, v in rows.items() if "igemm_conv_kernel" in k]
+    cls = [v for k, v in rows.items() if "igemm_conv_kernel" in k or "deconv_fwd_kernel" in k]   # bench.py's class 0
     n = sum(v["launches"] for v in cls)
     summary = {"igemm_conv_kernel_class": {
         "launches": n,
