@@ -15,14 +15,17 @@
 //    (MT * Cin / 2 VGPRs, loaded once per workgroup): the main loop issues no weight traffic at all.
 //  * The MFMA takes the weight fragment as its first operand (D[channel][pixel]), so a lane ends up with quads of
 //    four consecutive channels of one pixel.
-//  * The pixel tile (32 pixels x Cin) is staged once per workgroup through LDS, double buffered, one barrier per tile;
-//    the next tile's global loads are issued before the MFMA loop and land in LDS after the epilogue.
+//  * The pixel tile (32 pixels x Cin) is staged once per workgroup through LDS, double buffered, one barrier per tile.
 //  * The K axis is walked in the order channel(s, h) = 8 (s / 4) + 4 h + s % 4 (s: k-step, h = lane / 32, the half of
 //    the 32x32x2 MFMA's K pair): a lane's four consecutive k-steps are four consecutive channels, i.e. one 16-byte LDS
 //    read feeds four MFMA steps, and the staging writes are 16-byte writes of what the global load returned.
-//  * Epilogue per 32-channel tile: quads -> wave-private LDS block -> rows of 8 lanes x 16 B = one pixel's 32
-//    channels = one full 128-byte line per pixel (direct quad stores cover 32 lines x 32 B per instruction, measured
-//    slower in the general kernel), bias / BN affine / ReLU in the same pass.  No workgroup barrier in the epilogue.
+//  * The affine epilogue is folded into the contraction (scaled weights, constant term as the C operand of a tile's
+//    first MFMAs); what remains is the ReLU.
+//  * A finished tile goes quads -> wave-private LDS blocks (16-byte writes straight from the accumulator registers)
+//    and is read back as pieces of 8 pixels x 32 channels = 8 whole 128-byte lines (direct quad stores cover 32 lines
+//    x 32 B per instruction, measured slower in the general kernel).  No workgroup barrier in the epilogue.
+//  * Everything except the MFMAs and that write -- the next tile's global loads and staging, the B-operand reads, the
+//    previous tile's piece reads, ReLU and stores -- is placed slot by slot INSIDE the MFMA stream (see the kernel).
 #include "common.h"
 #include "deconv_fwd.h"
 #include <stdlib.h>
