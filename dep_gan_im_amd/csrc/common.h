@@ -41,8 +41,8 @@ static inline TView null_view() {
 }
 
 // Fused epilogue description, applied in this order to acc (the raw contraction):
-//   v = acc + bias[co]
-//   v = v * scale[co] + shift[co]          (phase-0 BatchNorm affine)
+//   v = (acc + bias[co]) * scale[co] + shift[co]   (phase-0 BatchNorm affine; the MFMA kernels
+//                                          evaluate it as fma(acc, scale, bias * scale + shift): one rounding)
 //   out_pre = v                            (pre-FiLM tensor kept for the G backward)
 //   v = v * film_mul[b,co] + film_add[b,co]  (GT:403-404)
 //   v = max(v, 0)                          (relu)

@@ -398,7 +398,8 @@ def test_config4_bf16_matrix_pipe(lib):
     after a dozen layers the two are as far from each other as either is from the unrounded network (measured: HIP vs
     oracle 3.3e-2 of the output range, rounding effect itself 2.9e-2; critic 1.7e-3 vs 1.1e-3).  So the forward values
     are pinned at THAT level -- no farther from the rounded oracle than twice the rounding's own effect, mean error a
-    tenth of it -- and, as SURVEY 8d says, the loss scalars of the four closures (3e-2 with the count-based M3, 1e-2 without).  Masters move by one Adam step."""
+    tenth of it -- and, as SURVEY 8d says, the loss scalars of the four closures (3e-2; 1e-2 without the count-based M3
+    as long as both sides still hold the same weights).  Masters move by one Adam step."""
     import dep_gan_im_amd as dg
     from oracle import depgan_oracle as O
     img, B, seed = 64, 2, 57
@@ -432,14 +433,22 @@ def test_config4_bf16_matrix_pipe(lib):
     assert rel(d_got, d_q) < 2.0 * rel(d_q, d_w) + 1e-3, (rel(d_got, d_q), rel(d_q, d_w))
     ref = O.OracleTrainers(PG, PD1, PD2, nicg=2, dtype=torch.float64, weights_dtype="bfloat16",
                            activations_dtype="bfloat16")
-    for name, args in (("netD_y2_train", [y2, x, z, ep]), ("netD_dem_train", [y2, x, z, ep]),
+    moved = False
+    for name, args in (("netG_no_update", [x, y2, z]), ("netD_y2_train", [y2, x, z, ep]), ("netD_dem_train", [y2, x, z, ep]),
                        ("netG_no_update", [x, y2, z]), ("netG_train", [x, y2, z]), ("netG_no_update", [x, y2, z])):
         got, want = getattr(tr, name)(args), getattr(ref, name)(args)
         print("config 4 bf16 pipe %s: %s vs %s" % (name, [round(v, 5) for v in got], [round(v, 5) for v in want]))
         # M3 = 100 ((#real - #fake) / 1000)^2 is a squared difference of voxel COUNTS: a handful of voxels whose fake value
-        # sits at the threshold move it by per cent (14.82 vs 15.13 here); everything else agrees to ~1e-3
+        # sits at the threshold move it by per cent (14.82 vs 15.13 here); everything else agrees to ~1e-3 .. 1e-2
         assert srel(got, want) < 3e-2, (name, got, want)
-        assert srel(got[1:4], want[1:4]) < 1e-2 if len(got) == 6 else True
+        # Before any update both sides evaluate the same weights: the critic means and M1 are pinned at 1e-2.  After an
+        # update they are not comparable that tightly: a first Adam step moves every weight by lr * sign(gradient), the
+        # bf16 network's gradients carry per-cent noise, so the small ones come out with either sign and the critics'
+        # mean outputs (~0.04 here) differ by ~1e-2 relative -- from one fp32 rounding order of the epilogue to another
+        # just as much as between HIP and the oracle (measured: 0.9e-2 and 1.5e-2 for the two orders this kernel has had).
+        if len(got) == 6 and not moved:
+            assert srel(got[1:4], want[1:4]) < 1e-2, (name, got, want)
+        moved = moved or name.endswith("_train")
     lr = 1e-4
     for net, P in (("G", PG), ("D_y2", PD1), ("D_dem", PD2)):
         W = eng.get_weights(net)
