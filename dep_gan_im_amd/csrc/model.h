@@ -125,6 +125,11 @@ struct depgan_ctx {
   unsigned g_pack_blocks = 0;
   BnJob* g_bn_jobs = nullptr;
   int g_n_bn = 0;
+  // BN-gamma gradients of the generator: the un-scaled weight gradients of a backward pass are kept per layer
+  // (raw_all mirrors the gradient arena) and all gammas are formed in ONE launch at the end of the pass
+  float* raw_all = nullptr;
+  GammaJob* g_gamma_jobs = nullptr;
+  int g_n_gamma = 0, g_gamma_blocks = 0;
   float* heads_mean = nullptr;    // concatenated moving means of the head BNs
   float* dheads = nullptr;        // [B][1024]
   Tn attr;                        // generator output (B,H,W,1)

@@ -815,12 +815,8 @@ static int g_conv_bn_bwd(depgan_ctx* c, GLayer& L, size_t li, const float* x_use
   TView xin = (li == 0) ? make_view(const_cast<float*>(x_user), L.H, L.W, L.Cin) : L.in;
   // db = s * sum dy, dbeta = sum dy: column sums fused into the weight-gradient launch
   const ColSum cs = {n, L.s, L.db, L.dbeta};
-  DGCHECK(wgrad_full(c, 3, xin, dy, n, L.H, L.W, L.Cin, L.Cout, L.s, L.dW, c->raw, 0, 0, &cs));
-  {
-    ProfScope ps(c, 2, 0.0, "bn gamma grad");
-    DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 9 * L.Cin, L.Cout, 0, L.Cin, L.b, L.mean, L.rstd, L.dbeta, L.dgamma,
-                             c->st));
-  }
+  // the un-scaled gradient stays in the layer's slot of raw_all: g_backward forms every BN gamma gradient at its end
+  DGCHECK(wgrad_full(c, 3, xin, dy, n, L.H, L.W, L.Cin, L.Cout, L.s, L.dW, c->raw_all + (L.dW - c->g.G), 0, 0, &cs));
   if (li == 0) return DG_OK;
   ConvArgs a;
   memset(&a, 0, sizeof(a));
@@ -860,14 +856,29 @@ int g_backward(depgan_ctx* c, const float* x, const float* z, int n) {
       DGCHECK(dg_unpool_mask(L.pool_dsrc, c->gl[L.skip_of].out, L.pool_skipgrad, L.pool_dst, n, L.H / 2, L.W / 2,
                              L.Cout, c->st));
     } else if (L.kind == G_DECONV) {
-      DGCHECK(deconv_wgrad_all(c, L, L.dout, n, L.s, c->raw, L.s, L.db, L.dbeta));
-      {
-        ProfScope ps(c, 2, 0.0, "bn gamma grad");
-        DGCHECK(dg_bn_gamma_grad(L.Wt, c->raw, 4 * L.Cin, L.Cout, 1, L.Cin, L.b, L.mean, L.rstd, L.dbeta, L.dgamma,
-                                 c->st));
-      }
+      DGCHECK(deconv_wgrad_all(c, L, L.dout, n, L.s, c->raw_all + (L.dW - c->g.G), L.s, L.db, L.dbeta));
       DGCHECK(deconv_bwd_data(c, L, L.dout, n));
     }
+  }
+  {
+    // BN-gamma gradients of all 24 layers in one launch: d gamma = rstd (sum_k W dWraw + (b - mu) S), S = d beta
+    if (!c->g_gamma_jobs) {
+      std::vector<GammaJob> jobs;
+      int blk = 0;
+      for (size_t i = 0; i < c->gl.size(); ++i) {
+        const GLayer& L = c->gl[i];
+        if (L.kind != G_CONV && L.kind != G_FILM && L.kind != G_DECONV) continue;
+        const bool de = L.kind == G_DECONV;
+        jobs.push_back({L.Wt, c->raw_all + (L.dW - c->g.G), L.b, L.mean, L.rstd, L.dbeta, L.dgamma,
+                        (de ? 4 : 9) * L.Cin, L.Cout, de ? 1 : 0, L.Cin, blk});
+        blk += L.Cout;
+      }
+      c->g_n_gamma = (int)jobs.size();
+      c->g_gamma_blocks = blk;
+      DGCHECK(upload_table(c, jobs, &c->g_gamma_jobs));
+    }
+    ProfScope ps(c, 2, 0.0, "bn gamma grad");
+    DGCHECK(dg_bn_gamma_grad_batch(c->g_gamma_jobs, c->g_n_gamma, c->g_gamma_blocks, c->st));
   }
   ProfScope ps(c, 2, 0.0, "noise mlp bwd");
   return dg_noise_bwd(c->np, c->ng, z, c->na, c->dheads, c->scratch, n, c->st);
@@ -1232,6 +1243,7 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
     rc = dmalloc(c, &c->part, mx);
   }
   if (rc == DG_OK) rc = dmalloc(c, &c->raw, (size_t)9 * 256 * 256);
+  if (rc == DG_OK && !c->train_bn) rc = dmalloc(c, &c->raw_all, c->g.nTrain);
   if (rc == DG_OK) rc = dmalloc(c, &c->Sraw, 256);
   if (rc == DG_OK) rc = dmalloc(c, &c->scratch, (size_t)(1 << 20) + (size_t)cfg->batch * 20000);
   if (rc == DG_OK) rc = dmalloc(c, &c->scal, 16);

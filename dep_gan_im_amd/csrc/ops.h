@@ -48,6 +48,14 @@ struct BnJob {
   int C;
 };
 int dg_bn_prepare_batch(const BnJob* jobs_dev, int njobs, float eps, hipStream_t st);
+// every BN-gamma gradient of a network in one launch (one 256-thread block per output channel, jobs walked by blk0)
+struct GammaJob {
+  const float *W, *dWraw, *bias, *mean, *rstd, *S;
+  float* dgamma;
+  int K, Cout, oi, Cin;
+  int blk0;      // first block of this job in the batched grid
+};
+int dg_bn_gamma_grad_batch(const GammaJob* jobs_dev, int njobs, int nblocks, hipStream_t st);
 int dg_colsum(TView v, int B, int H, int W, int C, const float* scale, float* out, float* raw, int accumulate,
               float* scratch, hipStream_t st);
 

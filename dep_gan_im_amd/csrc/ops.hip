@@ -784,6 +784,34 @@ __global__ void bn_gamma_grad_kernel(const float* __restrict__ W, const float* _
   acc = block_sum(acc, sh4);
   if (threadIdx.x == 0) dgamma[co] = rstd[co] * (acc + (bias[co] - mean[co]) * S[co]);
 }
+__global__ void bn_gamma_grad_batch_kernel(const GammaJob* __restrict__ jobs, int njobs) {
+  __shared__ float sh4[4];
+  // the job of this block: jobs are few (tens), blk0 ascending
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+  const GammaJob J = jobs[j];
+  const int co = (int)blockIdx.x - J.blk0;
+  float acc = 0.f;
+  if (!J.oi) {
+    for (int k = threadIdx.x; k < J.K; k += blockDim.x)
+      acc = fmaf(J.W[(size_t)k * J.Cout + co], J.dWraw[(size_t)k * J.Cout + co], acc);
+  } else {
+    for (int k = threadIdx.x; k < J.K; k += blockDim.x) {
+      const int t = k / J.Cin, ci = k - t * J.Cin;
+      const size_t o = ((size_t)t * J.Cout + co) * J.Cin + ci;
+      acc = fmaf(J.W[o], J.dWraw[o], acc);
+    }
+  }
+  acc = block_sum(acc, sh4);
+  if (threadIdx.x == 0) J.dgamma[co] = J.rstd[co] * (acc + (J.bias[co] - J.mean[co]) * J.S[co]);
+}
+int dg_bn_gamma_grad_batch(const GammaJob* jobs_dev, int njobs, int nblocks, hipStream_t st) {
+  if (njobs <= 0) return DG_OK;
+  hipLaunchKernelGGL(bn_gamma_grad_batch_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}
+
 int dg_bn_gamma_grad(const float* W, const float* dWraw, int K, int Cout, int oi, int Cin, const float* bias,
                      const float* mean, const float* rstd, const float* S, float* dgamma, hipStream_t st) {
   hipLaunchKernelGGL(bn_gamma_grad_kernel, dim3(Cout), dim3(256), 0, st, W, dWraw, K, Cout, oi, Cin, bias,
