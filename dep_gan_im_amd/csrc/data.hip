@@ -129,10 +129,16 @@ __global__ __launch_bounds__(256) void minmax_final_kernel(const float* __restri
 // channel 1 of x (npix, 2): v -> clip((v - min) / (max - min) * (max_o - min_o) + min_o, min_o, max_o), GT:140-144
 __global__ __launch_bounds__(256) void flair_normalise_kernel(float* __restrict__ xo, size_t npix,
                                                               const float* __restrict__ mm, float min_o, float max_o) {
+  // hipcc's __fmul_rn / __fadd_rn are plain `*` / `+` inside a header and may be contracted into an FMA; operators
+  // written HERE under the pragma are what keeps every operation individually rounded, as NumPy's statement sequence
+  // is (GT:140-144)
+#pragma clang fp contract(off)
   const float mn = mm[0], rng = __fsub_rn(mm[1], mm[0]), span = __fsub_rn(max_o, min_o);
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
     float v = xo[2 * i + 1];
-    v = __fadd_rn(__fmul_rn(__fdiv_rn(__fsub_rn(v, mn), rng), span), min_o);
+    const float q = __fdiv_rn(v - mn, rng);
+    const float t = q * span;
+    v = t + min_o;
     v = (v > max_o) ? max_o : v;
     v = (v < min_o) ? min_o : v;
     xo[2 * i + 1] = v;

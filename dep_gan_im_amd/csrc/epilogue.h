@@ -21,9 +21,16 @@ __device__ __forceinline__ long view_off(const TView& v, int b, int y, int x) {
   return (long)b * v.sB + (long)y * v.sY + (long)x * v.sX;
 }
 
-// FiLM pre-activation; kept as one function so forward and backward evaluate
-// the sign of v with the identical instruction sequence.
-__device__ __forceinline__ float film_preact(float u, float fmul, float fadd) { return __fadd_rn(__fmul_rn(u, fmul), fadd); }
+// FiLM pre-activation v = u * mul + add (GT:403-404: a Multiply layer, then an Add layer -- two roundings).  One
+// function, so that the forward pass (ReLU of v) and the backward pass (sign of v recomputed from the stored u) take the
+// same decision on every unit.  The contraction pragma is what guarantees it: hipcc's __fmul_rn / __fadd_rn are plain
+// `x * y` / `x + y` and were contracted into v_pk_fma_f32 in film_bwd_partial but not in the convolution epilogue (found
+// by the mask-pinned gradient test: one unit of 1.6e7 at 256x256 decided differently in the two passes).
+__device__ __forceinline__ float film_preact(float u, float fmul, float fadd) {
+#pragma clang fp contract(off)
+  const float p = u * fmul;
+  return p + fadd;
+}
 
 __device__ __forceinline__ void epi_store(const ConvArgs& a, const EpiChan& c, int b, int oy, int ox, int co,
                                           float acc) {

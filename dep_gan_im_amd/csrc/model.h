@@ -182,6 +182,11 @@ struct depgan_ctx {
         *n_rstdh = nullptr;
   float *n_dl = nullptr, *n_dflat = nullptr, *n_dl1 = nullptr, *n_da0 = nullptr, *n_dl0 = nullptr;
 
+  // ---- parity-test surface (depgan_debug_capture / depgan_debug_tensor) ----
+  bool dbg_capture = false;
+  float* dbg_mixed[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool dbg_mixed_valid = false;
+
   // ---- profiling ----
   bool prof_on = false;
   std::vector<ProfRec> recs;

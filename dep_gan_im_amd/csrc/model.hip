@@ -1000,6 +1000,16 @@ static int critic_enqueue(depgan_ctx* c, int which, const float* y2, const float
     DGCHECK(dg_critic_inputs(y2, x, c->cfg.nicg, c->attr.p, ep, c->d_in, B, HW0, which, c->st));
   }
   DGCHECK(d_forward(c, D, c->d_in, 0, 3 * B));
+  if (c->dbg_capture) {
+    // parity-test surface: the mixed pass's activations, before the penalty's u-forward overwrites them in place
+    for (int l = 0; l < 11; ++l) {
+      const size_t per = c->d_act[l].per_sample();
+      if (!c->dbg_mixed[l]) DGCHECK(dmalloc(c, &c->dbg_mixed[l], (size_t)B * per));
+      HIPCHECK(hipMemcpyAsync(c->dbg_mixed[l], c->d_act[l].p + (size_t)2 * B * per, (size_t)B * per * sizeof(float),
+                              hipMemcpyDeviceToDevice, c->st));
+    }
+    c->dbg_mixed_valid = true;
+  }
   // upstream: real -1/B, fake +1/B, mixed 1 (GT:540-547)
   DGCHECK(d_backward_chain(c, D, 0, 3 * B, c->coefs, B, 2 * B, B, c->g0));
   float* u0 = c->d_in + 2 * B * HW0;
@@ -1522,6 +1532,81 @@ int depgan_profile_dump(depgan_ctx* c, const char* path) {
     fprintf(f, "%d,%s,%.4f,%.3f\n", r.klass, r.label, t, r.flops * 1e-9);
   }
   fclose(f);
+  return DG_OK;
+}
+
+// ---- parity-test surface ----
+int depgan_debug_capture(depgan_ctx* c, int on) {
+  c->dbg_capture = on != 0;
+  if (!on) c->dbg_mixed_valid = false;
+  return DG_OK;
+}
+
+int depgan_debug_tensor(depgan_ctx* c, const char* name, float* host, long cap, int shape[4]) {
+  if (!c || !name || !shape) { dg_set_error("debug_tensor: null argument"); return DG_ERR_ARG; }
+  const std::string nm(name);
+  const int B = c->cfg.batch;
+  TView v = null_view();
+  int N = 0, H = 0, W = 0, C = 0;
+  auto rest = [&](const char* pre) { return nm.substr(strlen(pre)); };
+  auto starts = [&](const char* pre) { return nm.compare(0, strlen(pre), pre) == 0; };
+  if (nm == "g/heads" || nm == "g/noise_a0" || nm == "g/noise_a1") {
+    float* p = nm == "g/heads" ? c->na.heads : (nm == "g/noise_a0" ? c->na.a0 : c->na.a1);
+    v = make_view(p, 1, 1, 1024);
+    N = B; H = 1; W = 1; C = 1024;
+  } else if (starts("g/out/") || starts("g/u/")) {
+    const bool want_u = starts("g/u/");
+    const std::string ln = want_u ? rest("g/u/") : rest("g/out/");
+    for (const GLayer& L : c->gl) {
+      if (L.name != ln) continue;
+      if (want_u) {
+        if (L.kind != G_FILM || !L.u.p) break;
+        v = L.u.view();
+        H = L.H; W = L.W;
+      } else {
+        v = L.out;
+        H = L.kind == G_POOL ? L.H / 2 : (L.kind == G_DECONV ? 2 * L.H : L.H);
+        W = L.kind == G_POOL ? L.W / 2 : (L.kind == G_DECONV ? 2 * L.W : L.W);
+      }
+      N = B; C = L.Cout;
+      break;
+    }
+  } else if (starts("d/act/") || starts("d/mixed/")) {
+    const bool mixed = starts("d/mixed/");
+    const std::string ln = mixed ? rest("d/mixed/") : rest("d/act/");
+    for (size_t l = 0; l < c->dl.size(); ++l) {
+      if (c->dl[l].name != ln) continue;
+      if (mixed) {
+        if (!c->dbg_mixed_valid || !c->dbg_mixed[l]) { dg_set_error("debug_tensor: %s was not captured (depgan_debug_capture)", name); return DG_ERR_ARG; }
+        v = make_view(c->dbg_mixed[l], c->dl[l].H, c->dl[l].W, c->dl[l].Cout);
+        N = B;
+      } else {
+        v = c->d_act[l].view();
+        N = c->NB3;
+      }
+      H = c->dl[l].H; W = c->dl[l].W; C = c->dl[l].Cout;
+      break;
+    }
+  }
+  if (!v.p || N == 0) { dg_set_error("debug_tensor: unknown tensor '%s'", name); return DG_ERR_ARG; }
+  shape[0] = N; shape[1] = H; shape[2] = W; shape[3] = C;
+  if (!host) return DG_OK;
+  const long need = (long)N * H * W * C;
+  if (cap < need) { dg_set_error("debug_tensor: %s needs %ld floats, the buffer holds %ld", name, need, cap); return DG_ERR_ARG; }
+  if (v.sY != (long)W * v.sX || v.sB != (long)H * v.sY) { dg_set_error("debug_tensor: %s is not a channel slice of a dense tensor", name); return DG_ERR_UNSUPPORTED; }
+  HIPCHECK(hipStreamSynchronize(c->st));
+  if (v.sX == C) {
+    HIPCHECK(hipMemcpy(host, v.p, (size_t)need * sizeof(float), hipMemcpyDeviceToHost));
+    return DG_OK;
+  }
+  // rows of C floats at a pitch of sX floats (a channel slice of a concat buffer) -> dense on the device, then down
+  float* tmp = nullptr;
+  HIPCHECK(hipMalloc((void**)&tmp, (size_t)need * sizeof(float)));
+  hipError_t e = hipMemcpy2D(tmp, (size_t)C * sizeof(float), v.p, (size_t)v.sX * sizeof(float), (size_t)C * sizeof(float),
+                             (size_t)N * H * W, hipMemcpyDeviceToDevice);
+  if (e == hipSuccess) e = hipMemcpy(host, tmp, (size_t)need * sizeof(float), hipMemcpyDeviceToHost);
+  hipFree(tmp);
+  if (e != hipSuccess) { dg_set_error("debug_tensor: copy of %s failed: %s", name, hipGetErrorString(e)); return DG_ERR_HIP; }
   return DG_OK;
 }
 

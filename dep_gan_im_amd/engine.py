@@ -397,6 +397,20 @@ class Engine:
         check(self.lib.depgan_last_sums(self.h, out), "depgan_last_sums")
         return [float(v) for v in out]
 
+    # ---- parity-test surface ----
+    def debug_capture(self, on=True):
+        """Keep a copy of the mixed pass's activations in every critic closure (depgan_debug_capture)."""
+        check(self.lib.depgan_debug_capture(self.h, 1 if on else 0), "depgan_debug_capture")
+
+    def debug_tensor(self, name):
+        """An internal tensor of the last closure as a dense (N,H,W,C) float32 array (depgan_debug_tensor)."""
+        shape = (C.c_int * 4)()
+        check(self.lib.depgan_debug_tensor(self.h, name.encode(), None, 0, shape), "depgan_debug_tensor")
+        out = np.empty(tuple(shape), np.float32)
+        check(self.lib.depgan_debug_tensor(self.h, name.encode(), C.c_void_p(out.ctypes.data), out.size, shape),
+              "depgan_debug_tensor")
+        return out
+
     # ---- profiling ----
     def profile(self, on):
         check(self.lib.depgan_profile_enable(self.h, 1 if on else 0))

@@ -23,7 +23,7 @@ typedef struct depgan_ctx depgan_ctx;
 /* ABI guard: bump when depgan_config or the meaning of an entry point changes.  depgan_create rejects a
  * depgan_config whose struct_size is not sizeof(depgan_config) of THIS header (a caller compiled or bound against an
  * older layout would otherwise make the library read past its struct). */
-#define DEPGAN_ABI_VERSION 2
+#define DEPGAN_ABI_VERSION 3
 int depgan_abi_version(void);
 size_t depgan_config_size(void);
 /* first 32 hex digits of the sha256 over the sources this binary was built from (dep_gan_im_amd/build.py::source_hash):
@@ -197,6 +197,28 @@ size_t depgan_data_prep_scratch_floats(int X, int Y, int Z);
 int depgan_data_prep_subject(const float* p1_dev, const float* f1_dev, const float* icv1_dev, const float* sl1_dev,
                              const float* p2_dev, const float* icv2_dev, const float* sl2_dev, int X, int Y, int Z,
                              int nicg, float* x_out_dev, float* y2_out_dev, float* scratch_dev, void* stream);
+
+/* ---- parity-test surface: the tensors a training closure left behind ----
+ * The step functions are piecewise linear in the ReLU signs and max-pool arg-maxes of the forward passes (GT:256-309
+ * activations, GT:322-335 pools; the gradient penalty of GT:543-549 differentiates through them twice).  A parity
+ * test that wants a bound EVERY evaluation must meet compares the gradients with a float64 restatement evaluated
+ * under the very masks this library used; these two calls hand them out.
+ * depgan_debug_capture(ctx, 1): from now on every critic closure keeps a copy of the post-ReLU activations of its
+ *   interpolated ("mixed", GT:538 / 557) pass, which the penalty's second pass otherwise overwrites in place.
+ * depgan_debug_tensor: copies one internal tensor to host memory as a dense (N, H, W, C) float32 array and reports
+ *   its shape; host_dst == NULL only reports the shape.  Names (layer names as in the reference, GT:256-309, 319-339):
+ *     "g/out/<layer>"   output of a generator trunk layer of the last generator pass: conv / FiLM block / deconv
+ *                       (post-ReLU), "skip1..3" (the pooled tensor), "gen_segmentation" (tanh output)
+ *     "g/u/<layer>"     BatchNorm output of a FiLM block's convolution (GT:402; kept by training passes only)
+ *     "g/heads"         the 14 noise-MLP head outputs, (N, 1, 1, 1024) in creation order (GT:363-395)
+ *     "g/noise_a0", "g/noise_a1"   post-ReLU trunk activations of the noise MLP (GT:358-359), (N, 1, 1, 1024)
+ *     "d/act/<layer>"   post-ReLU activations of critic layer dis_0a .. dis_8 of the last critic passes, 3*batch
+ *                       sample slots [real | fake | mixed] (a generator pass leaves D_y2(fake_y2) in slots [0, batch) and
+ *                       D_dem(attr) in [batch, 2 batch))
+ *     "d/mixed/<layer>" the captured copy of the mixed pass (batch samples; needs depgan_debug_capture)
+ * Status 1 for an unknown name, a tensor that was not captured, or cap_floats too small. */
+int depgan_debug_capture(depgan_ctx* ctx, int on);
+int depgan_debug_tensor(depgan_ctx* ctx, const char* name, float* host_dst, long cap_floats, int shape[4]);
 
 /* ---- single operators (unit-test surface; device pointers) ---- */
 /* path: 0 auto, 1 fp32 MFMA implicit GEMM, 2 direct, 3 bf16 MFMA implicit GEMM (both operands rounded to bf16, RNE),

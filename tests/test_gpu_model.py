@@ -2,14 +2,12 @@
 Gen_UNet2D / Dis_C2D_FCN1 predict, the four closures and post-step weights
 against the CPU oracle and the committed golden vectors.
 
-Tolerances.  north_star asks 1e-3 in fp32.  Forward quantities and the generator
-gradient meet it outright.  The WGAN-GP *critic* gradient is rounding-sensitive on
-inputs with exactly-flat regions (max-pool ties / ReLU kinks re-route whole
-gradient paths and the penalty multiplies them by ~1/norm): the CPU oracle's own
-fp32 and fp64 results differ by 1-4 % there (measured in test below).  So the critic
-gradient is checked (a) at 1e-3 on tie-free inputs and (b) on the reference-like
-masked inputs against the fp64 oracle with the oracle's own fp32-vs-fp64 spread as
-the yardstick."""
+Tolerances.  north_star asks 1e-3 in fp32.  Forward quantities meet it outright.
+Gradients are piecewise linear in the ReLU signs / max-pool arg-maxes of the forward
+passes; their parity is pinned in tests/test_gpu_masked.py (fp64 oracle under the HIP
+path's own decisions: per tensor 1e-4 on EVERY seed, measured ~5e-6).  What is left
+here is one free comparison on reference-like inputs (flat regions: pool ties, ReLU
+kinks) with the oracle's own fp32-vs-fp64 spread as yardstick."""
 import os
 
 import numpy as np
@@ -42,20 +40,27 @@ def _setup(img, B, seed, noisy=False):
     return PG, PD1, PD2, x, y2, z, ep
 
 
-def _engine(img, B, PG, PD1, PD2):
+def _engine(img, B, PG, PD1, PD2, **kw):
     from dep_gan_im_amd import Engine
-    eng = Engine(B, img, img, 1)
+    eng = Engine(B, img, img, 1, **kw)
     eng.set_weights("G", PG)
     eng.set_weights("D_y2", PD1)
     eng.set_weights("D_dem", PD2)
     return eng
 
 
+# every mode that appears on the bench line is held to the same parity tests: the native fp32 matrix pipe and the opt-in
+# `f32_split = 6` (fp32 operands split exactly into bf16 terms, six products on the bf16 pipe; include/depgan.h)
+SPLIT = pytest.mark.parametrize("split", [0, 6], ids=["native", "split6"])
+
+
+@SPLIT
 @pytest.mark.parametrize("name", ["small_64_b2", "full_256_b2"])
-def test_forward_and_eval_match_golden(lib, name):
+def test_forward_and_eval_match_golden(lib, name, split):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     PG, PD1, PD2, x, y2, z, ep = _setup(int(g["img"]), int(g["B"]), int(g["seed"]))
-    eng = _engine(int(g["img"]), int(g["B"]), PG, PD1, PD2)
+    eng = _engine(int(g["img"]), int(g["B"]), PG, PD1, PD2, f32_split=split)
+    assert eng.f32_split == split
     w = eng.get_weights("G")
     assert all(np.array_equal(w[k], PG[k]) for k in PG)            # set/get round trip is exact
     attr = eng.g_forward(x, z).cpu().numpy()
@@ -70,48 +75,11 @@ def test_forward_and_eval_match_golden(lib, name):
     eng.close()
 
 
-def test_gradients_tie_free_inputs_1e3(lib):
-    """Per-tensor 1e-3 on the critic and generator gradients at 64x64 on tie-free inputs.  The critic gradient is
-    piecewise linear in ~1e6 ReLU signs / pool arg-maxes: an evaluation in which a unit sits within rounding of its kink
-    is off by 1e-3..5e-2 on single tensors for ANY fp32 arithmetic, the CPU oracle's included (tests/test_gpu_steps.py
-    has the statistics), so up to three seeds are tried per network: every tried seed must stay bounded (whole-gradient
-    relative L2 < 5e-2) and one must meet 1e-3 on every tensor."""
-    from oracle import depgan_oracle as O
-
-    def l2(a, b):
-        return float(np.sqrt(sum(((a[k] - b[k]) ** 2).sum() for k in b) / sum((b[k] ** 2).sum() for k in b)))
-
-    ok = {"D_y2": False, "D_dem": False, "G": False}
-    for seed in (31, 33, 37):
-        if all(ok.values()):
-            break
-        PG, PD1, PD2, x, y2, z, ep = _setup(64, 2, seed, noisy=True)
-        eng = _engine(64, 2, PG, PD1, PD2)
-        for which, PD, key in (("D_y2", PD1, "y2"), ("D_dem", PD2, "dem")):
-            if ok[which]:
-                continue
-            out = eng.critic(which, y2, x, z, ep, update=False)
-            outs, grads, aux = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float64)
-            assert srel(out, outs) < 1e-3
-            gg = eng.get_grads(which)
-            assert l2(gg, grads) < 5e-2, (which, seed)
-            ok[which] = all(rel(gg[k], grads[k]) < 1e-3 for k in grads)
-        if not ok["G"]:
-            out = eng.generator(x, y2, z, "grads")
-            outs, grads = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float64)
-            _, g32 = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float32)
-            assert srel(out, outs) < 1e-3
-            gg = eng.get_grads("G")
-            assert l2(gg, grads) < 5e-2, ("G", seed)
-            # the generator gradient runs through both critics (ReLU / max-pool kinks): the oracle's own fp32 spread
-            spread = max(rel(g32[k], grads[k]) for k in grads)
-            ok["G"] = all(rel(gg[k], grads[k]) < max(2e-3, 3.0 * spread) for k in grads)
-        eng.close()
-    assert all(ok.values()), ok
-
-
-@pytest.mark.parametrize("img,B,seed", [(64, 2, 1), (256, 2, 3)])
+@pytest.mark.parametrize("img,B,seed", [(64, 2, 1)])
 def test_gradients_reference_like_inputs(lib, img, B, seed):
+    """FREE comparison (each side takes its own ReLU / arg-max decisions) on reference-like inputs, with the oracle's
+    own fp32-vs-fp64 spread as yardstick, and run-to-run bit reproducibility.  The bound every evaluation must meet is
+    in tests/test_gpu_masked.py (decisions pinned: per tensor 1e-4 on every seed, 64x64 and 256x256)."""
     from oracle import depgan_oracle as O
     PG, PD1, PD2, x, y2, z, ep = _setup(img, B, seed)
     eng = _engine(img, B, PG, PD1, PD2)
@@ -291,7 +259,8 @@ def test_two_channel_generator_input_nicg2(lib):
     eng.close()
 
 
-def test_reference_schedule_one_generator_iteration(lib):
+@SPLIT
+def test_reference_schedule_one_generator_iteration(lib, split):
     """schedule.train_epoch (GT:779-894) on the HIP engine vs the same schedule on the oracle closures,
     same RNG stream: critic outputs, the ten best-of-k losses, the chosen noise and the G losses."""
     import dep_gan_im_amd as dg
@@ -302,7 +271,8 @@ def test_reference_schedule_one_generator_iteration(lib):
     nets = [dg.Gen_UNet2D((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1))]
     for n, P in zip(nets, (PG, PD1, PD2)):
         n.set_weights(P)
-    tr = dg.build_trainers(*nets, batchSize=B)
+    tr = dg.build_trainers(*nets, batchSize=B, f32_split=split)
+    assert tr.engine.f32_split == split
     ref = O.OracleTrainers(PG, PD1, PD2, dtype=torch.float64)
     logs = []
     for t in (tr, ref):

@@ -1,14 +1,14 @@
 """GPU parity of multi-step behaviour through the C ABI: Adam beyond t = 1, three-step trajectories of each network
-against the fp64 oracle, the one-synchronisation generator iteration against the closure-by-closure schedule, and
-training-state checkpoints (resume is bit-identical).
+against the fp64 oracle (decisions pinned, every seed tight), the one-synchronisation generator iteration against the
+closure-by-closure schedule, and training-state checkpoints (resume is bit-identical).
 
-Why the trajectory tolerances look the way they do.  Keras Adam with beta_1 = 0 (GT:549) moves every weight by
+Why the trajectory checks look the way they do.  Keras Adam with beta_1 = 0 (GT:549) moves every weight by
 lr_t * g / (sqrt(v) + eps): the first step is +-lr whatever |g| is, so an element whose gradient is zero to within
-rounding flips sign for free (2 lr apart) -- on both sides of any comparison, the CPU oracle's fp32 and fp64 runs
-included.  Weights are therefore compared (a) exactly, on gradients injected into the arena (the Adam kernel itself:
-v accumulation, lr_t(t), eps placement), and (b) along real trajectories through quantities that are smooth in the
-gradient -- the second-moment arena v after three steps, the last gradient m, the loss scalars of steps 2 and 3 (they
-see the updated weights) -- plus the weights themselves on the elements whose gradient is not rounding-sized."""
+rounding takes either sign for free (2 lr apart).  Weights are therefore compared (a) exactly, on gradients injected
+into the arena (the Adam kernel itself: v accumulation, lr_t(t), eps placement), and (b) along real trajectories
+through quantities that are smooth in the gradient -- the second-moment arena v after three steps, the last gradient
+m, the loss scalars of steps 2 and 3 (they see the updated weights) -- plus the weights themselves on the elements
+whose gradient is not rounding-sized, and the fraction of elements that took the other sign is bounded."""
 import os
 
 import numpy as np
@@ -34,12 +34,8 @@ def _setup(img, B, seed, nb=1, trained_regime=True):
     ~0.005-0.01.  The critics' last layer (dense_1, linear in the output) is rescaled until the norm is ~2, the regime
     the reference actually trains in; everything upstream of it keeps its initialisation.
 
-    What no construction removes (DESIGN.md section 2 has the table): the critic gradient is piecewise linear in the
-    activations' signs and arg-maxes, and a 256x256 evaluation has ~1.6e7 ReLU units -- the CPU oracle's OWN fp32 and
-    fp64 runs agree to 2e-6 (whole-gradient relative L2) when no unit sits within rounding of its kink and to 1e-3..5e-3
-    when some do, which at 256x256 is nearly always.  The tests therefore print both distances and require the HIP path
-    to be as close to fp64 as the CPU fp32 path is (a small multiple of that distance), with a tight floor for the
-    well-conditioned cases and an absolute cap that a wrong kernel cannot meet."""
+    The step is piecewise linear in the activations' signs and arg-maxes (a 256x256 evaluation has ~1.6e7 ReLU units):
+    free fp32-vs-fp64 comparisons are bimodal, so the trajectory test pins the decisions."""
     from oracle import depgan_oracle as O
     PG = O.init_generator(seed, bias_std=0.05)
     PD1 = O.init_critic(seed + 1, bias_std=0.05, img=img)
@@ -122,184 +118,69 @@ def _masked_weight_check(W, W0, Wref, G_list, lr, what):
 
 
 def _trajectory(which, seed):
-    """Three updates of one network on three different tie-free batches, HIP vs the fp64 oracle (and the oracle's own fp32
-    run as a yardstick).  Returns the worst per-step output error, Adam v / m errors after step 3 and weight errors."""
+    """Three updates of one network on three different tie-free batches: the HIP closures against the fp64 oracle
+    evaluated, at every step, under the decisions (ReLU signs, pool arg-maxes, L1 signs) the HIP step took
+    (tests/test_gpu_masked.py) and at the ORACLE's own weights -- two independent trajectories that share nothing but the
+    masks.  Returns per-step output errors, the Adam state errors after step 3 and the weight errors."""
+    import test_gpu_masked as TM
     from oracle import depgan_oracle as O
+    from oracle import manual as M
     img, B, lr = 64, 2, 1e-4
     PG, PD1, PD2, x, y2, z, ep = _setup(img, B, seed, nb=3)
     tr, nets = _trainers(img, B, PG, PD1, PD2)
+    eng = tr.engine
+    eng.debug_capture(True)
     cp = lambda P: {k: v.copy() for k, v in P.items()}      # noqa: E731
-    ref = O.OracleTrainers(cp(PG), cp(PD1), cp(PD2), dtype=torch.float64)
-    r32 = O.OracleTrainers(cp(PG), cp(PD1), cp(PD2), dtype=torch.float32)
-    P0 = {"G": PG, "D_y2": PD1, "D_dem": PD2}[which]
-    pick = lambda t: ({"G": t.optG, "D_y2": t.optD_y2, "D_dem": t.optD_dem}[which],     # noqa: E731
-                      {"G": t._PG, "D_y2": t._PDy2, "D_dem": t._PDdem}[which])
-    (opt, Wref), (opt32, W32) = pick(ref), pick(r32)
-    G_list, out_err, out_err32, out_first = [], 0.0, 0.0, 0.0
+    W = {"G": cp(PG), "D_y2": cp(PD1), "D_dem": cp(PD2)}     # the oracle's weights (float32, as Keras holds them)
+    P0 = cp(W[which])
+    names = O.trainable_names(P0)
+    opt = O.KerasAdam(names, lr, 0.0, 0.9)
+    out_err, G_list = [], []
     for t in range(3):
         s = slice(t * B, (t + 1) * B)
         if which == "G":
-            args, name = [x[s], y2[s], z[s]], "netG_train"
+            got = tr.netG_train([x[s], y2[s], z[s]])
+            masks = TM.hip_generator_masks(eng, x[s], y2[s], B)
+            want, grads = M.g_grads_manual(W["G"], W["D_y2"], W["D_dem"], x[s], y2[s], z[s], masks=masks)
+            cmp = (1, 2, 3)                                  # M3 / M4 are voxel counts at a threshold, GT:581-589
         else:
-            args, name = [y2[s], x[s], z[s], ep[s]], ("netD_y2_train" if which == "D_y2" else "netD_dem_train")
-        got, want, w32 = getattr(tr, name)(args), getattr(ref, name)(args), getattr(r32, name)(args)
-        out_err, out_err32 = max(out_err, srel(got, want)), max(out_err32, srel(w32, want))
-        if t == 0:
-            out_first = out_err        # same weights on both sides: forward parity alone
-        G_list.append({k: np.asarray(v, np.float64) for k, v in opt.m.items()})       # beta1 = 0: m is the gradient
-    assert tr.engine.adam_step(which) == 3
-    m, v = tr.engine.get_adam_state(which)
-    names = O.trainable_names(P0)
-    W = tr.engine.get_weights(which)
-    Wt = {k: W[k] for k in names}
-    l2, worst = _masked_weight_check(Wt, P0, {k: Wref[k] for k in names}, G_list, lr, "%s seed %d" % (which, seed))
-    res = dict(out=out_err, out32=out_err32, out_first=out_first,
-               v=max(rel(v[k], opt.v[k]) for k in names), m=max(rel(m[k], opt.m[k]) for k in names),
-               v32=max(rel(opt32.v[k], opt.v[k]) for k in names), m32=max(rel(opt32.m[k], opt.m[k]) for k in names),
-               l2=l2, worst=worst, flips=max(float(np.abs(W[k] - Wref[k]).max()) for k in names) / lr)
-    print("%s seed %d: outputs %.1e (oracle fp32 %.1e)  v %.1e (%.1e)  m %.1e (%.1e)  displacement L2 %.2e  masked %.2e lr"
-          % (which, seed, res["out"], res["out32"], res["v"], res["v32"], res["m"], res["m32"], l2, worst))
-    tr.engine.close()
+            got = getattr(tr, "netD_y2_train" if which == "D_y2" else "netD_dem_train")([y2[s], x[s], z[s], ep[s]])
+            masks = TM.hip_critic_masks(eng, B)
+            attr = O.g_predict(W["G"], x[s], z[s], dtype=torch.float64)
+            real, fake = TM.critic_real_fake(which, x[s].astype(np.float64), y2[s].astype(np.float64), attr)
+            want, grads, _ = M.critic_grads_manual(W[which], real, fake, ep[s], masks=masks)
+            cmp = (0, 1)
+        out_err.append(max(abs(got[i] - want[i]) / (abs(want[i]) + 1e-3) for i in cmp))
+        G_list.append({k: np.asarray(v, np.float64) for k, v in grads.items()})
+        opt.apply(W[which], grads)
+    assert eng.adam_step(which) == 3
+    m, v = eng.get_adam_state(which)
+    Wh = eng.get_weights(which)
+    l2, worst = _masked_weight_check({k: Wh[k] for k in names}, P0, {k: W[which][k] for k in names}, G_list, lr,
+                                     "%s seed %d" % (which, seed))
+    moved = np.concatenate([(np.abs(Wh[k] - W[which][k]) > 0.5 * lr).reshape(-1) for k in names])
+    res = dict(out=out_err, v=max(rel(v[k], opt.v[k]) for k in names), m=max(rel(m[k], opt.m[k]) for k in names),
+               l2=l2, worst=worst, resigned=float(moved.mean()))
+    print("%s seed %d: outputs per step %s  v %.1e  m %.1e  displacement L2 %.2e  masked %.2e lr  re-signed %.1e"
+          % (which, seed, ["%.1e" % e for e in out_err], res["v"], res["m"], l2, worst, res["resigned"]))
+    eng.close()
     return res
 
 
 @pytest.mark.parametrize("which", ["D_y2", "D_dem", "G"])
-def test_three_step_trajectory_vs_fp64_oracle(lib, which):
+@pytest.mark.parametrize("seed", [131, 149, 151])
+def test_three_step_trajectory_vs_fp64_oracle(lib, which, seed):
     """Three updates per network (GT:549 / 568 / 594: Adam state, lr_t(t), refreshed derived weights between steps)
-    against the fp64 oracle, on three seeds.  The critic gradient is piecewise linear in ~1e6 ReLU signs and pool
-    arg-maxes (see _setup): a run in which no unit sits within rounding of its kink reproduces fp64 to ~1e-5, one in
-    which some do is off by 1e-3..1e-1 on single tensors -- for the HIP path and for the CPU oracle's own fp32 run alike,
-    each on its own seeds (printed).  So: every seed must stay inside caps no wrong update rule could meet, and the
-    best seed must be tight."""
-    runs = [_trajectory(which, seed) for seed in (131, 149, 151)]
-    for r in runs:
-        # the first step's outputs are computed from identical weights: forward parity, kinks or not.  Three Adam steps
-        # move a weight by at most 3 lr on either side, whatever the size of its gradient (Adam normalises it), so one
-        # kink event in step 1 re-signs the updates of every weight whose gradient was rounding-sized and the outputs
-        # of steps 2-3 see that: they are only held to the same order of magnitude.
-        assert r["out_first"] < 1e-3 and r["out"] < 0.3 and r["flips"] <= 2.0 * 3 * 1.05 and r["l2"] < 0.5, r
-    best = min(runs, key=lambda r: r["m"])
-    if which != "G":
-        assert best["out"] < 1e-3 and best["m"] < 2e-3 and best["v"] < 2e-3, best
-        assert best["worst"] < 0.05 and best["l2"] < 1e-3, best   # weights: within 5 % of one step where the gradient is real
-    else:
-        # the generator's gradient runs through BOTH critics' kinks, three times over: no seed is event-free for the
-        # CPU fp32 oracle either (printed); its single-step gradient check is test_gpu_model.py's
-        assert min(r["out"] for r in runs) < 1e-3, runs
-
-
-def test_critic_gradient_exact_when_no_kink_event(lib):
-    """Single critic evaluation (first order + gradient-penalty double backward) at 64x64 on four seeds against the fp64
-    oracle, per tensor: exact (1e-4 on EVERY tensor) on the seeds where no unit sits within rounding of a kink, bounded
-    on all of them; the CPU oracle's own fp32 run is printed next to it."""
-    from dep_gan_im_amd import Engine
-    from oracle import depgan_oracle as O
-    img, B = 64, 2
-    tight = {"D_y2": 0, "D_dem": 0}
-    tight32 = {"D_y2": 0, "D_dem": 0}
-    seeds = (131, 137, 149, 151)
-    for seed in seeds:
-        PG, PD1, PD2, x, y2, z, ep = _setup(img, B, seed)
-        eng = Engine(B, img, img, 1)
-        for n, P in (("G", PG), ("D_y2", PD1), ("D_dem", PD2)):
-            eng.set_weights(n, P)
-        for which, PD, key in (("D_y2", PD1, "y2"), ("D_dem", PD2, "dem")):
-            out = eng.critic(which, y2, x, z, ep, update=False)
-            gg = eng.get_grads(which)
-            outs, g64, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float64)
-            _, g32, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float32)
-            assert srel(out, outs) < 1e-3
-            eb = max(rel(gg[k], g64[k]) for k in g64 if k.endswith("/bias") and np.abs(g64[k]).max() > 0)
-            ek = max(rel(gg[k], g64[k]) for k in g64 if k.endswith("/kernel"))
-            ek32 = max(rel(g32[k], g64[k]) for k in g64 if k.endswith("/kernel"))
-            print("seed %d %s: bias grads %.1e, kernel grads %.1e (oracle fp32: %.1e)" % (seed, which, eb, ek, ek32))
-            l2 = np.sqrt(sum(((gg[k] - g64[k]) ** 2).sum() for k in g64) / sum((g64[k] ** 2).sum() for k in g64))
-            l2_32 = np.sqrt(sum(((g32[k] - g64[k]) ** 2).sum() for k in g64) / sum((g64[k] ** 2).sum() for k in g64))
-            print("          whole-gradient rel-L2 %.1e (oracle fp32: %.1e)" % (l2, l2_32))
-            assert l2 < 5e-2 and ek < 0.3 and eb < 0.3, (seed, which, l2, ek, eb)
-            tight[which] += max(ek, eb) < 1e-4
-            tight32[which] += ek32 < 1e-4
-        eng.close()
-    print("all tensors within 1e-4 of fp64: HIP %s, oracle fp32 (kernels) %s of %d seeds" % (tight, tight32, len(seeds)))
-    assert min(tight.values()) >= 1, tight
-
-
-def test_tie_free_256_gradients_1e3(lib):
-    """The 1e-3 gradient check at the BASELINE resolution (256x256, batch 2, tie-free inputs, critics in the trained
-    regime of the penalty -- see _setup): both critics (first order + gradient-penalty double backward) and the
-    generator, every tensor, against the fp64 oracle; the oracle's own fp32-vs-fp64 difference is printed next to it."""
-    from dep_gan_im_amd import Engine
-    from oracle import depgan_oracle as O
-    img, B = 256, 2
-    PG, PD1, PD2, x, y2, z, ep = _setup(img, B, 231)
-    eng = Engine(B, img, img, 1)
-    for n, P in (("G", PG), ("D_y2", PD1), ("D_dem", PD2)):
-        eng.set_weights(n, P)
-
-    def stats(gg, g64, g32):
-        worst = max(rel(gg[k], g64[k]) for k in g64)
-        l2 = np.sqrt(sum(((gg[k] - g64[k]) ** 2).sum() for k in g64) / sum((g64[k] ** 2).sum() for k in g64))
-        o32 = max(rel(g32[k], g64[k]) for k in g64)
-        o32l2 = np.sqrt(sum(((g32[k] - g64[k]) ** 2).sum() for k in g64) / sum((g64[k] ** 2).sum() for k in g64))
-        return worst, l2, o32, o32l2
-
-    rows = []
-    for which, PD, key in (("D_y2", PD1, "y2"), ("D_dem", PD2, "dem")):
-        out = eng.critic(which, y2, x, z, ep, update=False)
-        outs, g64, aux = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float64)
-        _, g32, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float32)
-        assert 1.0 < float(np.mean(aux["norm"])) < 4.0
-        assert srel(out, outs) < 1e-3
-        rows.append((which,) + stats(eng.get_grads(which), g64, g32))
-    out = eng.generator(x, y2, z, "grads")
-    outs, g64 = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float64)
-    _, g32 = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float32)
-    assert srel(out, outs) < 1e-3
-    rows.append(("G",) + stats(eng.get_grads("G"), g64, g32))
-    for r in rows:
-        print("tie-free 256x256 %s: HIP-vs-fp64 max-rel %.2e, whole-gradient rel-L2 %.2e; oracle fp32-vs-fp64 %.2e / %.2e"
-              % r)
-    for which, worst, l2, o32, o32l2 in rows:
-        assert l2 < max(1e-3, 4 * o32l2), (which, l2, o32l2)      # 1e-3 outright when the oracle itself is that well off
-        assert l2 < 1e-2, (which, l2)                             # ... and never the size of a kernel bug
-        assert worst < max(1e-3, 5 * o32), (which, worst, o32)
-    eng.close()
-
-
-def test_reference_like_256_gradients_relative_l2(lib):
-    """Reference-like inputs (exactly flat regions outside the brain mask: max-pool ties, ReLU kinks) at 256x256, critics
-    at their random initialisation (penalty ill-conditioned, see _setup): whole-gradient relative L2 of HIP vs the fp64
-    oracle, with the oracle's own fp32-vs-fp64 L2 as yardstick (the conditioning itself -- the fp64 gradient's response to
-    a 1e-6 relative perturbation of the input -- is what tools/diag_critic_sensitivity.py prints)."""
-    from dep_gan_im_amd import Engine
-    from oracle import depgan_oracle as O
-    img, B, seed = 256, 2, 3
-    PG = O.init_generator(seed, bias_std=0.05)
-    PD1 = O.init_critic(seed + 1, bias_std=0.05, img=img)
-    PD2 = O.init_critic(seed + 2, bias_std=0.05, img=img)
-    x, y2, z, ep = O.synth_batch(seed + 5, B, img, img)
-    eng = Engine(B, img, img, 1)
-    for n, P in (("G", PG), ("D_y2", PD1), ("D_dem", PD2)):
-        eng.set_weights(n, P)
-
-    def l2(a, b):
-        return float(np.sqrt(sum(((a[k] - b[k]) ** 2).sum() for k in b) / sum((b[k] ** 2).sum() for k in b)))
-
-    for which, PD, key in (("D_y2", PD1, "y2"), ("D_dem", PD2, "dem")):
-        eng.critic(which, y2, x, z, ep, update=False)
-        gg = eng.get_grads(which)
-        _, g64, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float64)
-        _, g32, _ = O.critic_grads(PD, PG, y2, x, z, ep, key, dtype=torch.float32)
-        e_hip, e_o32 = l2(gg, g64), l2(g32, g64)
-        print("reference-like 256x256 %s: rel-L2 HIP-vs-fp64 %.2e, oracle fp32-vs-fp64 %.2e" % (which, e_hip, e_o32))
-        assert e_hip < 2.0 * e_o32 + 1e-3, (which, e_hip, e_o32)
-    eng.generator(x, y2, z, "grads")
-    gg = eng.get_grads("G")
-    _, g64 = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float64)
-    _, g32 = O.g_grads(PG, PD1, PD2, x, y2, z, dtype=torch.float32)
-    print("reference-like 256x256 G: rel-L2 HIP-vs-fp64 %.2e, oracle fp32-vs-fp64 %.2e" % (l2(gg, g64), l2(g32, g64)))
-    assert l2(gg, g64) < 3.0 * l2(g32, g64) + 1e-3
-    eng.close()
+    against the fp64 oracle under the HIP path's own decisions: EVERY seed must be tight.  What remains between the two
+    trajectories is fp32 rounding and one Adam property: with beta_1 = 0 the first step is lr * sign(g) whatever |g| is,
+    so an element whose gradient is rounding-sized (|g| < 1e-6 of the tensor's largest) can take the other sign -- those
+    elements are counted (`re-signed`) and bounded; they carry no gradient, so the following steps barely see them."""
+    r = _trajectory(which, seed)
+    assert r["out"][0] < 1e-4, r                       # same weights on both sides: forward parity alone
+    assert max(r["out"]) < 1e-3, r
+    assert r["m"] < 1e-3 and r["v"] < 2e-3, r          # the third gradient, taken at weights two updates downstream
+    assert r["worst"] < 0.05 and r["l2"] < 2e-2, r     # weights: within 5 % of one step wherever the gradient is real
+    assert r["resigned"] < 2e-3, r
 
 
 def test_fused_generator_iteration_equals_closure_schedule(lib):

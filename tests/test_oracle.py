@@ -74,6 +74,139 @@ def test_manual_backward_matches_autograd_generator():
         np.testing.assert_allclose(grads2[n], grads[n], rtol=1e-7, atol=1e-12 + 1e-9 * np.abs(grads[n]).max())
 
 
+# ---------------------------------------------------------------------------
+# Mask-pinned evaluation (oracle/manual.py `masks`): what the GPU gradient tests compare against
+# ---------------------------------------------------------------------------
+def _own_critic_masks(PD, img_nhwc):
+    """critic_masks() from the activations of an fp32 forward of the oracle itself (stands in for the HIP tensors)."""
+    taps = {}
+    with torch.no_grad():
+        O.d_forward_t(O.to_torch(PD), torch.tensor(img_nhwc), taps=taps)
+    return M.critic_masks({k: v.permute(0, 2, 3, 1).numpy() for k, v in taps.items()})
+
+
+def _flip_some(masks, rng, frac=0.02):
+    """Flips a few ReLU signs and moves a few arg-maxes inside their window: masks NO evaluation would produce."""
+    out = {}
+    for name, (m, idx) in masks.items():
+        m = m.clone()
+        flip = torch.from_numpy(rng.uniform(size=tuple(m.shape)) < frac)
+        m[flip] = ~m[flip]
+        if idx is not None:
+            idx = idx.clone()
+            W = m.shape[3]
+            move = torch.from_numpy(rng.uniform(size=tuple(idx.shape)) < frac)
+            # toggle the column inside the 2x2 window: even x -> x + 1, odd x -> x - 1
+            idx[move] = idx[move] + 1 - 2 * (idx[move] % W % 2)
+        out[name] = (m, idx)
+    return out
+
+
+def test_first_argmax_rule_is_torchs_and_handles_ties():
+    a = np.zeros((1, 2, 4, 4), np.float32)
+    a[0, 0, 0, 1] = a[0, 0, 1, 0] = 2.0                 # tie inside window (0,0): the first in row-major order wins
+    a[0, 1, 3, 3] = 1.0
+    idx = M.first_argmax_idx(a)
+    assert idx[0, 0, 0, 0] == 1 and idx[0, 0, 1, 1] == 2 * 4 + 2 and idx[0, 1, 1, 1] == 3 * 4 + 3
+    r = np.random.default_rng(0).integers(0, 3, size=(2, 3, 8, 8)).astype(np.float32)      # many ties
+    _, tidx = torch.nn.functional.max_pool2d(torch.from_numpy(r), 2, return_indices=True)
+    np.testing.assert_array_equal(M.first_argmax_idx(r), tidx.numpy())
+
+
+def test_masked_manual_critic_own_masks_reproduce_and_flipped_masks_match_autograd():
+    img, B, delta = 32, 2, 10.0
+    PD = O.init_critic(2, bias_std=0.05, img=img)
+    x, y2, z, ep = O.synth_batch(5, B, img, img)
+    rng = np.random.default_rng(1)
+    real = (y2 + 0.02 * rng.uniform(size=y2.shape)).astype(np.float32)
+    fake = (x + 0.02 * rng.uniform(size=x.shape)).astype(np.float32)
+    mixed = (ep * real + (1 - ep) * fake).astype(np.float32)
+    own = tuple(_own_critic_masks(PD, a) for a in (real, fake, mixed))
+    outs0, g0, aux0 = M.critic_grads_manual(PD, real, fake, ep, delta)
+    outs1, g1, aux1 = M.critic_grads_manual(PD, real, fake, ep, delta, masks=own)
+    # tie-free inputs: the fp32 forward's masks ARE the fp64 evaluation's masks -> identical results
+    np.testing.assert_allclose(outs1, outs0, rtol=1e-12)
+    for n in g0:
+        np.testing.assert_allclose(g1[n], g0[n], rtol=1e-9, atol=1e-14)
+    # masks no forward pass would produce: the hand-derived backward must still be the derivative of the masked forward
+    masks = tuple(_flip_some(m, rng) for m in own)
+    outs2, g2, aux2 = M.critic_grads_manual(PD, real, fake, ep, delta, masks=masks)
+    T = O.to_torch(PD, torch.float64, requires_grad=True)
+    r, f = (torch.tensor(a, dtype=torch.float64).permute(0, 3, 1, 2) for a in (real, fake))
+    e = torch.tensor(ep, dtype=torch.float64).reshape(-1, 1, 1, 1)
+    mx = (e * r + (1 - e) * f).requires_grad_(True)
+    out_r, _ = M.d_forward_store(T, r, masks[0])
+    out_f, _ = M.d_forward_store(T, f, masks[1])
+    out_m, _ = M.d_forward_store(T, mx, masks[2])
+    (gm,) = torch.autograd.grad(out_m.sum(), mx, create_graph=True)
+    gp = ((torch.sqrt((gm ** 2).sum((1, 2, 3))) - 1.0) ** 2).mean()
+    loss = out_f.mean() - out_r.mean() + delta * gp
+    names = O.trainable_names(PD)
+    gs = torch.autograd.grad(loss, [T[n] for n in names], allow_unused=True)
+    assert abs(float(gp.detach()) - aux2["gp"]) < 1e-12 and abs(aux2["gp"] - aux0["gp"]) > 1e-9      # the flips are visible
+    for n, g in zip(names, gs):
+        want = np.zeros_like(g2[n]) if g is None else g.detach().numpy()
+        np.testing.assert_allclose(g2[n], want, rtol=1e-7, atol=1e-12 + 1e-9 * np.abs(want).max(), err_msg=n)
+
+
+def test_masked_manual_generator_matches_autograd_of_the_masked_forward():
+    img, B = 32, 2
+    # (seed chosen so that the fp32 and the fp64 forward take the same side of every kink: with most seeds one of the
+    # ~3e5 units does not -- 1 / 2 / 3 / 4 / 6 give 2 / 0 / 1 / 1 / 1 differing decisions -- which is the very reason
+    # the GPU gradient tests pin the masks)
+    PG = O.init_generator(2, bias_std=0.05)
+    PD1 = O.init_critic(12, bias_std=0.05, img=img)
+    PD2 = O.init_critic(13, bias_std=0.05, img=img)
+    x, y2, z, ep = O.synth_batch(5, B, img, img)
+    rng = np.random.default_rng(3)
+    x = (x + 0.02 * rng.uniform(size=x.shape)).astype(np.float32)
+    y2 = (y2 + 0.02 * rng.uniform(size=y2.shape)).astype(np.float32)
+    # the tensors depgan_debug_tensor hands out, from an fp32 oracle forward
+    taps = {}
+    T32 = O.to_torch(PG)
+    with torch.no_grad():
+        attr = O.g_forward_t(T32, torch.tensor(x), torch.tensor(z), taps=taps).numpy()
+        heads = O.noise_mlp(T32, torch.tensor(z))
+        st32 = M.g_forward_store(T32, torch.tensor(x).permute(0, 3, 1, 2), torch.tensor(z))[1]
+    outs = {k: v.permute(0, 2, 3, 1).numpy() for k, v in taps.items() if k.startswith(("gen_", "de_gen"))}
+    for k in ("de_gen_9", "de_gen_11", "de_gen_15"):        # taps hold the concatenation; the deconv part comes first
+        outs[k] = outs[k][..., :st32[k].shape[1]]
+    us = {k[:-2]: v.permute(0, 2, 3, 1).numpy() for k, v in st32.items() if k.endswith("/u")}
+    hcat = np.concatenate([heads["noise_2_" + sfx].numpy() for sfx, _ in O.NOISE_HEADS], axis=1)
+    mg = M.generator_masks(outs, us, hcat, st32["noise"]["a0"].numpy(), st32["noise"]["a1"].numpy(), attr, x, y2)
+    md1 = _own_critic_masks(PD1, (x[..., 0:1] + attr).astype(np.float32))
+    md2 = _own_critic_masks(PD2, attr)
+    o0, g0 = M.g_grads_manual(PG, PD1, PD2, x, y2, z)
+    o1, g1 = M.g_grads_manual(PG, PD1, PD2, x, y2, z, masks=(mg, md1, md2))
+    np.testing.assert_allclose(o1, o0, rtol=1e-9)
+    worst = max(float(np.abs(g1[n] - g0[n]).max() / (np.abs(g0[n]).max() + 1e-30)) for n in g0)
+    assert worst < 1e-9, worst       # own masks: the fp32 forward's decisions are the fp64 evaluation's here
+    # perturbed masks against autograd through the masked forward
+    mg2 = dict(mg)
+    for k, v in mg.items():
+        if v.dtype == torch.bool:
+            v = v.clone()
+            flip = torch.from_numpy(rng.uniform(size=tuple(v.shape)) < 0.02)
+            v[flip] = ~v[flip]
+            mg2[k] = v
+    md1b, md2b = _flip_some(md1, rng), _flip_some(md2, rng)
+    o2, g2 = M.g_grads_manual(PG, PD1, PD2, x, y2, z, masks=(mg2, md1b, md2b))
+    TG = O.to_torch(PG, torch.float64, requires_grad=True)
+    TD1, TD2 = O.to_torch(PD1, torch.float64), O.to_torch(PD2, torch.float64)
+    xt = torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2)
+    y2t = torch.tensor(y2, dtype=torch.float64).permute(0, 3, 1, 2)
+    at, _ = M.g_forward_store(TG, xt, torch.tensor(z, dtype=torch.float64), masks=mg2)
+    d1, _ = M.d_forward_store(TD1, xt[:, 0:1] + at, md1b)
+    d2, _ = M.d_forward_store(TD2, at, md2b)
+    diff = at - (y2t - xt[:, 0:1])
+    loss = -d1.mean() - d2.mean() + 100.0 * (mg2["sign"].to(torch.float64) * diff).mean()
+    names = O.trainable_names(PG)
+    gs = torch.autograd.grad(loss, [TG[n] for n in names], allow_unused=True)
+    for n, g in zip(names, gs):
+        want = np.zeros_like(g2[n]) if g is None else g.detach().numpy()
+        np.testing.assert_allclose(g2[n], want, rtol=1e-7, atol=1e-12 + 1e-9 * np.abs(want).max(), err_msg=n)
+
+
 def test_semantics_phase0_bn_is_affine_and_m3_m4_have_no_gradient():
     """BN inference affine; M3/M4 (GT:581-589) contribute no gradient."""
     img = 32
