@@ -100,9 +100,12 @@ def cpu_baseline(sample_batch):
                              "sample": "BASELINE configs[0]: netG forward only, batch 4, 256x256x1, median of 5"}}
 
 
-def pmc_traffic(batch):
-    """HBM bytes per launch of the igemm class from the committed PMC passes over this same command
-    (tools/pmc_traffic.py; counters cannot be read from inside the process being timed)."""
+def pmc_traffic(batch, launches_per_step):
+    """HBM bytes per launch of the convolution class from the committed PMC passes (tools/pmc_traffic.py; counters
+    cannot be read from inside the process being timed).  The passes run this file with DEPGAN_BENCH_STEP_ONLY=1, i.e.
+    over canonical steps and nothing else, so the population is the one `algorithmic_bytes_per_launch` describes: the
+    file is refused unless its launch count is a whole number of steps of THIS build (a kernel added to or removed from
+    the step since the passes were taken makes the count stop dividing)."""
     best = None
     for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
         if f.endswith("pmc_traffic.json"):
@@ -111,7 +114,52 @@ def pmc_traffic(batch):
         return None, "no PMC pass for this configuration"
     with open(os.path.join(ROOT, "profiles", best)) as fh:
         d = json.load(fh)
-    return round(d["igemm_conv_kernel_class"]["hbm_bytes_per_launch"]), "profiles/" + best
+    cls = d["igemm_conv_kernel_class"]
+    n = int(cls.get("launches", 0))
+    if not d.get("step_only") or launches_per_step <= 0 or n == 0 or n % launches_per_step:
+        return None, ("profiles/%s refused: %d class launches is not a whole number of canonical steps of %d launches "
+                      "(or the passes were not taken with DEPGAN_BENCH_STEP_ONLY=1)" % (best, n, launches_per_step))
+    return round(cls["hbm_bytes_per_launch"]), "profiles/%s, %d launches = %d steps x %d" % (
+        best, n, n // launches_per_step, launches_per_step)
+
+
+def dominant_kernel(eng, steps):
+    """The convolution class split by kernel instantiation (the names rocprofv3 --kernel-trace --stats prints), from the
+    HIP-event records of the profiled steps: the instantiation with the largest share of the step, and inside it the
+    one layer shape that dominates."""
+    import csv
+    import tempfile
+    fd, path = tempfile.mkstemp(suffix=".csv")
+    os.close(fd)
+    try:
+        eng.profile_dump(path)
+        rows = [r for r in csv.DictReader(open(path)) if int(r["class"]) == 0]
+    finally:
+        os.remove(path)
+    if not rows:
+        return None
+    by_k, by_s = {}, {}
+    for r in rows:
+        for d, key in ((by_k, r["kernel"]), (by_s, (r["kernel"], r["label"]))):
+            a = d.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += float(r["ms"])
+            a[2] += float(r["gflop"])
+    kname, (kn, kms, kgf) = max(by_k.items(), key=lambda kv: kv[1][1])
+    (_, sname), (sn, sms, sgf) = max(((k, v) for k, v in by_s.items() if k[0] == kname), key=lambda kv: kv[1][1])
+
+    def line(n, ms, gf):
+        tf = gf / ms if ms > 0 else 0.0            # GFLOP / ms = TFLOP/s
+        return {"launches_per_step": n // steps, "avg_launch_us": round(ms / n * 1e3, 2),
+                "gflop_per_launch": round(gf / n, 3), "ms_per_step": round(ms / steps, 3),
+                "achieved": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA, 4)}
+    out = {"kernel": kname, "unit": "TFLOP/s", "peak": PEAK_F32_MFMA}
+    out.update(line(kn, kms, kgf))
+    out["recompute"] = ("gflop_per_launch / avg_launch_us / %.1f; the average duration of this kernel name in "
+                        "profiles/*_kernel_stats.csv (rocprofv3 --kernel-trace --stats over the same command with "
+                        "DEPGAN_BENCH_STEP_ONLY=1) must agree with avg_launch_us" % PEAK_F32_MFMA)
+    out["largest_shape"] = dict(shape=sname, **line(sn, sms, sgf))
+    return out
 
 
 def bench_config4(dg, torch, dev, B, steps=5):
@@ -215,10 +263,16 @@ def bench_split(dg, torch, dev, B, x, y2, z, ep, steps=5):
         torch.cuda.synchronize()
         gf = (time.perf_counter() - t1) / 5 * 1e3
         eng.close()
+        eq = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
+        # this mode runs on the bf16 matrix pipe and is priced against THAT pipe: `mode` bf16 products per fp32 MAC make
+        # its peak 2500 / mode TFLOP/s fp32-equivalent (417 for six products), not the fp32 pipe's 157.3
         out["products_%d" % mode] = {
             "ms_per_step": round(ms, 3), "slices_per_s": round(B / (ms * 1e-3), 1),
             "ms_per_step_by_class": {"conv": round(c_ms, 3), "wgrad_fp32": round(w_ms, 3), "other": round(o_ms, 3)},
-            "conv_class_tflops_fp32_equivalent": round(c_fl / (c_ms * 1e-3) / 1e12, 1) if c_ms > 0 else 0.0,
+            "conv_class_tflops_fp32_equivalent": round(eq, 1),
+            "roofline": {"bound": "mfma", "pipe": "bf16 (v_mfma_f32_32x32x16_bf16), %d products per fp32 MAC" % mode,
+                         "achieved": round(eq, 1), "peak": round(2500.0 / mode, 1), "unit": "TFLOP/s fp32-equivalent",
+                         "frac": round(eq / (2500.0 / mode), 4)},
             "g_forward_ms": round(gf, 3)}
     return out
 
@@ -401,14 +455,17 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-        dp = DataParallel()
+        # one rank per GPU: the library's own RCCL communicator (ncclAllReduce issued from C on the engine's stream); the
+        # process group above carries the 128-byte id, the barrier and the max-over-ranks of the timing
+        dp = DataParallel(host_staging=one_gpu)
 
     B = args.batch
     # deliberately different seeds per rank: build_trainers(dist=dp) must make the replicas identical (rank 0's weights)
     netG = dg.Gen_UNet2D((256, 256, 1), (32, 1), 32, 1, seed=1 + 100 * rank)
     netD1 = dg.Dis_C2D_FCN1((256, 256, 1), seed=2 + 100 * rank)
     netD2 = dg.Dis_C2D_FCN1((256, 256, 1), seed=3 + 100 * rank)
-    tr = dg.build_trainers(netG, netD1, netD2, batchSize=B, delta=10.0, lrD=1e-4, lrG=1e-4, IM_TRSH=0.5, dist=dp,
+    # the workload is DEP-GAN-IM (irregularity map): IM_TRSH = 0.178 (GT:25-29; 0.5 is the probability-map setting)
+    tr = dg.build_trainers(netG, netD1, netD2, batchSize=B, delta=10.0, lrD=1e-4, lrG=1e-4, IM_TRSH=0.178, dist=dp,
                            device=dev)
     x, y2, z, ep = [torch.from_numpy(a).to(dev) for a in synth(1000 + rank, B)]
 
@@ -436,6 +493,25 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
+    single_ms = None
+    if dp is not None and not os.environ.get("DEPGAN_BENCH_STEP_ONLY"):
+        # the same step without its collectives, on an engine of its own (replicas must not diverge), max over ranks
+        n1 = [dg.Gen_UNet2D((256, 256, 1), (32, 1), 32, 1, seed=1), dg.Dis_C2D_FCN1((256, 256, 1), seed=2),
+              dg.Dis_C2D_FCN1((256, 256, 1), seed=3)]
+        t1 = dg.build_trainers(*n1, batchSize=B, IM_TRSH=0.178, device=dev)
+        for i in range(2 + args.steps):
+            if i == 2:
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+            t1.netD_y2_train([y2, x, z, ep])
+            t1.netD_dem_train([y2, x, z, ep])
+            t1.netG_train([x, y2, z])
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - ts) / args.steps * 1e3
+        t1.engine.close()
+        t = torch.tensor([single_ms], dtype=torch.float64, device=None if one_gpu else dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        single_ms = float(t.item())
 
     # ---- roofline of the dominant kernel class, HIP events on the engine's stream ----
     eng = tr.engine
@@ -449,9 +525,27 @@ def main():
     ot_ms, ot_n, _ = eng.profile_read(2)
     if rank == 0 and os.environ.get("DEPGAN_PROFILE_DUMP"):
         eng.profile_dump(os.environ["DEPGAN_PROFILE_DUMP"])     # per-launch labelled CSV (layer shapes) of two steps
+    dominant = dominant_kernel(eng, 2) if rank == 0 else None
     eng.profile(False)
     eng.profile_reset()
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # DEPGAN_BENCH_STEP_ONLY=1: the process runs canonical steps and NOTHING else (no generator-forward / generator-
+    # iteration probes, no extra engines) -- the command the rocprofv3 passes of tools/collect_profiles.sh wrap, so that
+    # their per-kernel averages and PMC sums cover exactly the launches `roofline` describes
+    step_only = bool(os.environ.get("DEPGAN_BENCH_STEP_ONLY"))
+    if step_only:
+        if rank == 0:
+            print(json.dumps({"metric": "2D slices/sec (G+2D+GP train step), 256x256x1 fp32", "step_only": True,
+                              "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                              "canonical_steps_run": args.warmup + args.steps + 2,
+                              "conv_class": {"launches_per_step": conv_n // 2, "achieved": round(achieved, 2),
+                                             "avg_launch_us": round(conv_ms / max(conv_n, 1) * 1e3, 2),
+                                             "algorithmic_bytes_per_launch": round(conv_bytes / max(conv_n, 1))},
+                              "dominant_kernel": dominant}), flush=True)
+        if dp is not None:
+            torch.distributed.destroy_process_group()
+        return 0
     # north_star's secondary target: generator forward alone (A1/A12, 23.513 GFLOP/slice) at this batch
     torch.cuda.synchronize()
     out = eng.g_forward(x, z)
@@ -505,7 +599,7 @@ def main():
     config5 = None
     if world == 1 and rank == 0 and not os.environ.get("DEPGAN_BENCH_SKIP_CONFIG5"):
         config5 = bench_config5(dg, torch, dev, B)
-    traffic, traffic_src = pmc_traffic(B)
+    traffic, traffic_src = pmc_traffic(B, conv_n // 2)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; "
@@ -514,6 +608,7 @@ def main():
                 "kernel": "igemm_conv_kernel (all shapes: fwd / bwd-data / GP u-forward) + the 3 deconv_fwd_kernel "
                           "launches of the generator forward (the convolution class; `traffic` is the igemm kernels')",
                 "avg_launch_us": round(conv_ms / max(conv_n, 1) * 1e3, 2), "launches_per_step": conv_n // 2,
+                "dominant_kernel": dominant,
                 "wgrad": {"achieved": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2) if wg_ms > 0 else 0.0,
                           "ms_per_step": round(wg_ms / 2, 3)},
                 "ms_per_step": {"igemm_conv": round(conv_ms / 2, 3), "wgrad": round(wg_ms / 2, 3),
@@ -539,9 +634,18 @@ def main():
                 "roofline": roofline}
         if dp is not None:
             line["collectives"] = {"per_step": 3, "issued": dp.calls,
+                                   "expected": 3 * (args.warmup + args.steps + 2) + 2 * 12 * 3,
+                                   "path": "direct RCCL: ncclAllReduce from libdepgan on the engine's stream" if dp.direct
+                                           else "torch.distributed hook (%s)" % ("host staging, gloo" if one_gpu else "nccl"),
+                                   "rccl_nranks": eng.rccl_info()[0] if dp.direct else None,
                                    "message_floats": [int(eng.arena(n, 2)[1]) + 8 for n in ("D_y2", "D_dem", "G")]}
+            if single_ms is not None:
+                # self-check for the first multi-GPU run: the same step on the same GPU without the collectives (a fresh
+                # single-rank engine, max over ranks) -- weak-scaling efficiency is its ratio to the timed step
+                line["collectives"]["ms_per_step_without_collectives"] = round(single_ms, 3)
+                line["scaling_efficiency"] = round(single_ms / ms, 4)
         if args.n1_value:
-            line["scaling_efficiency"] = round(value / (world * args.n1_value), 4)
+            line["scaling_efficiency_vs_n1_value"] = round(value / (world * args.n1_value), 4)
         if config4 is not None:
             line["config4"] = config4
         if config5 is not None:

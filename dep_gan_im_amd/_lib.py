@@ -20,11 +20,13 @@ EXPORTS = [
     "depgan_uresnet_eval", "depgan_profile_read_bytes", "depgan_g_eval_multi", "depgan_eval_accumulate", "depgan_eval_counts",
     "depgan_data_prep_scratch_floats", "depgan_data_prep_subject", "depgan_abi_version", "depgan_config_size",
     "depgan_set_allreduce", "depgan_get_adam_step", "depgan_set_adam_step", "depgan_gen_iteration", "depgan_eval_divide",
-    "depgan_source_hash", "depgan_debug_capture", "depgan_debug_tensor",
+    "depgan_source_hash", "depgan_debug_capture", "depgan_debug_tensor", "depgan_rccl_unique_id", "depgan_rccl_init",
+    "depgan_rccl_broadcast", "depgan_rccl_info", "depgan_rccl_shutdown",
 ]
 
 ABI_VERSION = 3          # DEPGAN_ABI_VERSION of the include/depgan.h this binding was written against
 MAX_MULTI, MAX_CRITIC_STEPS = 32, 256
+RCCL_ID_BYTES = 128
 
 
 class Config(C.Structure):
@@ -133,6 +135,11 @@ def load():
     lib.depgan_uresnet_step.argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint, fp]
     lib.depgan_uresnet_eval.argtypes = [vp, vp, vp, vp, C.c_int, fp]
     lib.depgan_debug_capture.argtypes = [vp, C.c_int]
+    lib.depgan_rccl_unique_id.argtypes = [vp]
+    lib.depgan_rccl_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.depgan_rccl_broadcast.argtypes = [vp, vp, C.c_long, C.c_int]
+    lib.depgan_rccl_info.argtypes = [vp, ip, ip, C.POINTER(C.c_long)]
+    lib.depgan_rccl_shutdown.argtypes = [vp]
     lib.depgan_debug_tensor.argtypes = [vp, C.c_char_p, vp, C.c_long, ip]
     _lib = lib
     return lib

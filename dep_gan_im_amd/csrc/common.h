@@ -142,6 +142,36 @@ void dg_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Launcher-side state that belongs to a DEVICE, not to the process: a kernel's dynamic-LDS attribute, its occupancy, the
+// CU count.  A process may hold contexts on several GPUs (Engine(device=...)): function-local statics would give the
+// second device the first one's numbers and never set its attributes.
+#define DG_MAX_DEVICES 64
+static inline int dg_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= DG_MAX_DEVICES) return -1;
+  return d;
+}
+struct DgOncePerDevice {   // `if (once.need()) { set attribute ... }`; a device beyond the table is set every time
+  bool done[DG_MAX_DEVICES] = {};
+  bool need() {
+    const int d = dg_device_slot();
+    if (d < 0) return true;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+static inline int dg_cu_count() {   // CUs of the current device, asked once per device (the query is slower than a launch)
+  static int cus[DG_MAX_DEVICES] = {};
+  const int d = dg_device_slot();
+  if (d >= 0 && cus[d]) return cus[d];
+  int n = 256;
+  hipDeviceProp_t p;
+  if (d >= 0 && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount;
+  if (d >= 0) cus[d] = n;
+  return n;
+}
+
 // ---- conv plans -----------------------------------------------------------
 // How one convolution maps on the MFMA implicit-GEMM kernel.
 struct ConvPlan {
@@ -201,6 +231,8 @@ int dg_pack_weights(const ConvPlan& pl, const float* src, int srcI, int srcO, in
                     const float* kscale, float* dst, hipStream_t st);
 
 int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
+// name of the kernel instantiation dg_conv_igemm launches for (pl, a), as rocprofv3 prints it
+void dg_conv_igemm_name(const ConvPlan& pl, const ConvArgs& a, char* buf, size_t cap);
 int dg_conv_direct(int KS, const ConvArgs& a, hipStream_t st);
 
 // wgrad: returns number of chunks used through *nchunks; part must hold

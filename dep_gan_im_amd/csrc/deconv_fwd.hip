@@ -295,7 +295,9 @@ __global__ __launch_bounds__(256, 1) void deconv_fwd_kernel(DeconvArgs a) {
 template <int CIN, int MT, bool WIDE>
 int launch_w(const DeconvArgs& a, int ny, hipStream_t st) {
   using C = DCfg<CIN, MT>;
-  static int per_cu = 0;
+  static int per_cu_dev[DG_MAX_DEVICES] = {};   // occupancy and the LDS attribute belong to the device
+  const int slot = dg_device_slot();
+  int per_cu = slot >= 0 ? per_cu_dev[slot] : 0;
   if (!per_cu) {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv_fwd_kernel<CIN, MT, WIDE>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
@@ -307,18 +309,9 @@ int launch_w(const DeconvArgs& a, int ny, hipStream_t st) {
       if (v >= 1 && v < occ) occ = v;
     }
     per_cu = occ;
+    if (slot >= 0) per_cu_dev[slot] = occ;
   }
-  int cus = 256;
-  {
-    static int ncu = 0;
-    if (!ncu) {
-      int dev = 0;
-      hipDeviceProp_t p;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
-      if (ncu < 1) ncu = 256;
-    }
-    cus = ncu;
-  }
+  const int cus = dg_cu_count();
   int gx = cus * per_cu / ny;
   if (gx > a.nTiles) gx = a.nTiles;
   if (gx < 1) gx = 1;

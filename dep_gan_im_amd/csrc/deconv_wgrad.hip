@@ -183,14 +183,7 @@ int ilog2_exact(int v) {
 // workgroups (= partial slabs) of a launch: the largest count <= 2 per CU whose share of the k-steps is a whole
 // number of ring rounds (small problems get fewer workgroups); 0 when the steps are not a multiple of the ring depth
 int pick_chunks(long total_steps, int ny) {
-  static int cus = 0;     // asked once: the property query is far slower than a launch
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-      cus = p.multiProcessorCount;
-  }
+  const int cus = dg_cu_count();
   const int want = 2 * cus / ny;
   for (int n = want; n >= 1; --n)
     if (total_steps % ((long)n * DEPTH) == 0) return n;

@@ -117,11 +117,10 @@ template <int KS, int COG, int G>
 static int launch_direct(const ConvArgs& a, hipStream_t st) {
   constexpr int TW = 16 + KS - 1;
   constexpr size_t lds = (size_t)(8 * TW * TW + KS * KS * 8 * COG * G) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DgOncePerDevice once;
+  if (once.need()) {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_direct_kernel<KS, COG, G>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   dim3 grid((unsigned)(cdiv(a.W, 16) * cdiv(a.H, 16) * a.B), (unsigned)cdiv(a.Cout, COG * G));
   hipLaunchKernelGGL((conv_direct_kernel<KS, COG, G>), grid, dim3(256), lds, st, a);
@@ -225,11 +224,10 @@ template <int KS>
 static int launch_cout1(const ConvArgs& a, hipStream_t st) {
   constexpr int TW = 32 + KS - 1;
   constexpr size_t lds = (size_t)(8 * TW * 40 + 8 * KS * 8) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DgOncePerDevice once;
+  if (once.need()) {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_kernel<KS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   dim3 grid((unsigned)(cdiv(a.W, 32) * cdiv(a.H, 32) * a.B));
   hipLaunchKernelGGL((conv_cout1_kernel<KS>), grid, dim3(256), lds, st, a);

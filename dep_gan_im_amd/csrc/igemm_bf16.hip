@@ -415,11 +415,10 @@ static int launch_split(const ConvArgs& a, hipStream_t st) {
   constexpr size_t lds_k = (size_t)NPL * (TW * TW + TAPG * 32) * SPLIT_ROWB(NPL);
   constexpr size_t lds_e = (size_t)4 * 64 * (32 + 4) * sizeof(float);
   constexpr size_t lds = lds_k > lds_e ? lds_k : lds_e;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DgOncePerDevice once;
+  if (once.need()) {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_split_kernel<KS, TAPG, NPL>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   ConvArgs b = a;
   b.lgx = cdiv(a.W, 16) * cdiv(a.H, 16) * a.B;
@@ -439,11 +438,10 @@ static int launch_bf16(const ConvArgs& a, hipStream_t st) {
   constexpr size_t lds_k = (size_t)(TW * TW + TAPG * 32) * 80;
   constexpr size_t lds_e = (size_t)4 * 64 * (32 + 4) * sizeof(float);
   constexpr size_t lds = lds_k > lds_e ? lds_k : lds_e;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DgOncePerDevice once;
+  if (once.need()) {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<KS, TAPG>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   ConvArgs b = a;
   b.lgx = cdiv(a.W, 16) * cdiv(a.H, 16) * a.B;

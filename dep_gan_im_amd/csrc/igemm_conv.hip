@@ -402,43 +402,51 @@ ConvPlan dg_plan_conv_items(int KS, int Cin, int Cout, long items) {
   return p;
 }
 
+// Persistent workgroups: as many as are resident per CU (3 by registers, fewer where the LDS tile is large), each
+// walking ~total / G items.  The per-thread staging geometry and address arithmetic (about 550 instructions per
+// item) is then computed once per workgroup.  Every workgroup of the grid MUST be resident: one that has to wait
+// for a slot runs its whole share after the others have finished (752 workgroups at 2 resident per CU: +20 %).
+// Measured per layer on one device (tools/cmp_persist.py): 3x3 layers +1..4 %, 5x5 layers +3..5 %, 1x1 -9 %.
+// DEPGAN_IGEMM_PERSIST=<workgroups per CU> forces a setting for all shapes (0 = never) for A/B measurements.
+// Returns the grid size: < total means the persistent instantiation.
+static long igemm_grid(int KS, int CK, size_t lds, long total) {
+  const char* e = getenv("DEPGAN_IGEMM_PERSIST");
+  // the 3x3 persistent instantiation is compiled for 3 resident workgroups per CU (4 with 8-channel chunks); the
+  // others take what their registers allow (2)
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > (KS == 3 ? (CK == 8 ? 4 : 3) : 2)) per_cu = (KS == 3 ? (CK == 8 ? 4 : 3) : 2);
+  if (KS == 1) per_cu = 0;   // K is one chunk: nothing to amortise, measured -0.17 ms per step when persistent
+  if (e) per_cu = atoi(e) < per_cu ? atoi(e) : per_cu;
+  const long cap = 256L * per_cu;
+  // any launch with more items than resident workgroups: also at 1.3 items per workgroup the persistent grid beats
+  // dispatching the overflow as a second wave of workgroups (64x64 64->64 at batch 32, 1024 items: 85 -> 105 TFLOP/s)
+  return (per_cu > 0 && total > cap) ? cap : total;
+}
+
+// name_out != nullptr: only report which instantiation the launch would take (profile records, bench.py's
+// dominant-kernel line: the names rocprofv3 prints), launch nothing
 template <int MF, int KS, int CK, int TAPG>
-static int launch_variant(const ConvArgs& a, hipStream_t st) {
+static int launch_variant(const ConvArgs& a, hipStream_t st, char* name_out = nullptr, size_t name_cap = 0) {
   constexpr int TW = 16 + KS - 1;
   constexpr size_t lds_k = (size_t)(TW * TW * (CK + 4) + TAPG * MF * (CK + 4)) * sizeof(float);
   constexpr size_t lds_e = (size_t)4 * 64 * (MF + 4) * sizeof(float);  // epilogue transpose
   constexpr size_t lds = lds_k > lds_e ? lds_k : lds_e;
-  static bool attr_set = false;
-  if (!attr_set) {
+  ConvArgs b = a;
+  b.lgx = cdiv(a.W, 16) * cdiv(a.H, 16) * a.B;
+  b.lgy = cdiv(a.Cout, MF) * (a.groups > 1 ? a.groups : 1);
+  const long total = (long)b.lgx * b.lgy;
+  const long G = igemm_grid(KS, CK, lds, total);
+  if (name_out) {
+    snprintf(name_out, name_cap, "igemm_conv_kernel<%d,%d,%d,%d,%s>", MF, KS, CK, TAPG, G < total ? "true" : "false");
+    return DG_OK;
+  }
+  // the dynamic-LDS attribute is per device: a process may hold contexts on several GPUs (Engine(device=...))
+  static DgOncePerDevice once;
+  if (once.need()) {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_kernel<MF, KS, CK, TAPG, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_kernel<MF, KS, CK, TAPG, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  ConvArgs b = a;
-  b.lgx = cdiv(a.W, 16) * cdiv(a.H, 16) * a.B;
-  b.lgy = cdiv(a.Cout, MF) * (a.groups > 1 ? a.groups : 1);
-  long total = (long)b.lgx * b.lgy;
-  long G = total;
-  {
-    // Persistent workgroups: as many as are resident per CU (3 by registers, fewer where the LDS tile is large), each
-    // walking ~total / G items.  The per-thread staging geometry and address arithmetic (about 550 instructions per
-    // item) is then computed once per workgroup.  Every workgroup of the grid MUST be resident: one that has to wait
-    // for a slot runs its whole share after the others have finished (752 workgroups at 2 resident per CU: +20 %).
-    // Measured per layer on one device (tools/cmp_persist.py): 3x3 layers +1..4 %, 5x5 layers +3..5 %, 1x1 -9 %.
-    // DEPGAN_IGEMM_PERSIST=<workgroups per CU> forces a setting for all shapes (0 = never) for A/B measurements.
-    const char* e = getenv("DEPGAN_IGEMM_PERSIST");
-    // the 3x3 persistent instantiation is compiled for 3 resident workgroups per CU; the others take what their
-    // registers allow (2)
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > (KS == 3 ? (CK == 8 ? 4 : 3) : 2)) per_cu = (KS == 3 ? (CK == 8 ? 4 : 3) : 2);
-    if (KS == 1) per_cu = 0;   // K is one chunk: nothing to amortise, measured -0.17 ms per step when persistent
-    if (e) per_cu = atoi(e) < per_cu ? atoi(e) : per_cu;
-    const long cap = 256L * per_cu;
-    // any launch with more items than resident workgroups: also at 1.3 items per workgroup the persistent grid beats
-    // dispatching the overflow as a second wave of workgroups (64x64 64->64 at batch 32, 1024 items: 85 -> 105 TFLOP/s)
-    if (per_cu > 0 && total > cap) G = cap;
   }
   if (G < total)
     hipLaunchKernelGGL((igemm_conv_kernel<MF, KS, CK, TAPG, true>), dim3((unsigned)G), dim3(256), lds, st, b);
@@ -446,6 +454,27 @@ static int launch_variant(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((igemm_conv_kernel<MF, KS, CK, TAPG, false>), dim3((unsigned)G), dim3(256), lds, st, b);
   HIPCHECK(hipGetLastError());
   return DG_OK;
+}
+
+static int dispatch_variant(const ConvPlan& pl, const ConvArgs& a, hipStream_t st, char* name_out, size_t name_cap) {
+  switch (pl.variant) {
+    case 0: return launch_variant<32, 3, 16, 9>(a, st, name_out, name_cap);
+    case 1: return launch_variant<16, 3, 16, 9>(a, st, name_out, name_cap);
+    case 2: return launch_variant<32, 5, 8, 25>(a, st, name_out, name_cap);
+    case 3: return launch_variant<16, 5, 16, 25>(a, st, name_out, name_cap);
+    case 4: return launch_variant<32, 1, 32, 1>(a, st, name_out, name_cap);
+    case 5: return launch_variant<16, 1, 16, 1>(a, st, name_out, name_cap);
+    case 8: return launch_variant<32, 3, 8, 9>(a, st, name_out, name_cap);
+  }
+  dg_set_error("dg_conv_igemm: bad variant %d", pl.variant);
+  return DG_ERR_ARG;
+}
+
+void dg_conv_igemm_name(const ConvPlan& pl, const ConvArgs& a, char* buf, size_t cap) {
+  if (cap) buf[0] = 0;
+  if (pl.variant < 0) { snprintf(buf, cap, "conv_direct"); return; }
+  if (pl.bf16) { snprintf(buf, cap, pl.variant >= 200 ? "igemm_split_kernel" : "igemm_bf16_kernel"); return; }
+  dispatch_variant(pl, a, nullptr, buf, cap);
 }
 
 int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
@@ -477,16 +506,7 @@ int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
     }
   }
   if (is_bf16) return dg_conv_igemm_bf16(pl, a, st);
-  switch (pl.variant) {
-    case 0: return launch_variant<32, 3, 16, 9>(a, st);
-    case 1: return launch_variant<16, 3, 16, 9>(a, st);
-    case 2: return launch_variant<32, 5, 8, 25>(a, st);
-    case 3: return launch_variant<16, 5, 16, 25>(a, st);
-    case 4: return launch_variant<32, 1, 32, 1>(a, st);
-    case 5: return launch_variant<16, 1, 16, 1>(a, st);
-    case 8: return launch_variant<32, 3, 8, 9>(a, st);
-  }
-  return DG_ERR_UNSUPPORTED;
+  return dispatch_variant(pl, a, st, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------

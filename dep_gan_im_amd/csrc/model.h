@@ -105,6 +105,7 @@ struct ProfRec {
   double flops;
   double bytes;   // algorithmic HBM bytes of the launch (operands read once, results written once)
   char label[56];
+  char kernel[48];   // kernel instantiation (class 0 / 1) as rocprofv3 names it; empty for the HBM-bound helpers
 };
 
 struct depgan_ctx {
@@ -156,6 +157,9 @@ struct depgan_ctx {
   depgan_allreduce_fn ar_fn = nullptr;   // all-reduce (sum) hook, enqueued on the stream (include/depgan.h)
   void* ar_user = nullptr;
   int world = 1;
+  void* rccl_comm = nullptr;       // ncclComm_t of the direct binding (depgan_rccl_init); takes precedence over ar_fn
+  long rccl_issued = 0;
+  int device = 0;                  // HIP device the context was created on
   float* host_stats = nullptr;     // pinned: un-normalised loss pieces of the updates of one call, fetched asynchronously
   int* best_dev = nullptr;         // arg-min of the best-of-k search (device) and its pinned host copy
   int* best_host = nullptr;
@@ -195,7 +199,8 @@ struct depgan_ctx {
 struct ProfScope {
   depgan_ctx* c;
   bool live;
-  ProfScope(depgan_ctx* c_, int klass, double flops, const char* label = "", double bytes = 0.0)
+  ProfScope(depgan_ctx* c_, int klass, double flops, const char* label = "", double bytes = 0.0,
+            const char* kernel = "")
       : c(c_), live(c_->prof_on) {
     if (!live) return;
     ProfRec r;
@@ -204,6 +209,8 @@ struct ProfScope {
     r.bytes = bytes;
     strncpy(r.label, label, sizeof(r.label) - 1);
     r.label[sizeof(r.label) - 1] = 0;
+    strncpy(r.kernel, kernel, sizeof(r.kernel) - 1);
+    r.kernel[sizeof(r.kernel) - 1] = 0;
     hipEventCreate(&r.a);
     hipEventCreate(&r.b);
     hipEventRecord(r.a, c->st);

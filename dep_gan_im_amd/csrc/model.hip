@@ -5,6 +5,7 @@
 // oracle/manual.py step for step.
 #include "model.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -126,7 +127,9 @@ int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
                                                       (a.ep.pool.p ? 0.25 : 0)) +
                                           4.0 * KS * KS * a.Cin * a.Cout);
   if (pl.variant >= 0) {
-    ProfScope ps(c, 0, fl, lb, by);
+    char kn[48] = "";
+    if (c->prof_on) dg_conv_igemm_name(pl, a, kn, sizeof(kn));
+    ProfScope ps(c, 0, fl, lb, by, kn);
     return dg_conv_igemm(pl, a, c->st);
   }
   ProfScope ps(c, 2, fl, lb);
@@ -152,7 +155,7 @@ int deconv_fwd_launch(depgan_ctx* c, const GLayer& L, TView out, const float* bi
   snprintf(lb, sizeof(lb), "conv k1 b%d %dx%d %d->%d x4", n, L.H, L.W, L.Cin, L.Cout);
   const double px = 4.0 * n * L.H * L.W;
   ProfScope ps(c, 0, 2.0 * n * L.H * L.W * (double)L.Cin * L.Cout * 4, lb,
-               px * L.Cin + 4 * (px * L.Cout + 4.0 * L.Cin * L.Cout));
+               px * L.Cin + 4 * (px * L.Cout + 4.0 * L.Cin * L.Cout), "deconv_fwd_kernel");
   return dg_deconv_fwd(d, n, c->st);
 }
 
@@ -1124,7 +1127,66 @@ static void critic_from_sums(const float s[4], float out[2]) {   // GT:540-541
 // ---- update plumbing: [all-reduce] -> async fetch of the loss pieces -> Adam -> derived state ----
 #define HOST_STATS_FLOATS (8 * (DEPGAN_MAX_CRITIC_STEPS + DEPGAN_MAX_MULTI + 2))
 
+// ---- direct RCCL binding: the few entry points, resolved at run time (no link dependency) ----
+namespace {
+struct NcclId { char internal[DEPGAN_RCCL_ID_BYTES]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+struct RcclApi {
+  int (*GetUniqueId)(NcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, NcclId, int) = nullptr;      // the id travels BY VALUE
+  int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+const int kNcclFloat = 7, kNcclSum = 0;   // ncclFloat32, ncclSum (rccl.h)
+
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.ok ? &api : nullptr;
+  tried = true;
+  // the copy that is already in the process first (PyTorch-ROCm loads its own librccl with its own HIP runtime: a
+  // second copy would talk to another runtime), then the system's
+  void* h = dlsym(RTLD_DEFAULT, "ncclAllReduce") ? RTLD_DEFAULT : nullptr;
+  if (!h) {
+    const char* e = getenv("DEPGAN_RCCL_LIB");
+    const char* names[] = {e, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names)
+      if (nm && (h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+  }
+  if (!h) { dg_set_error("RCCL: librccl.so is not loaded and cannot be opened (%s)", dlerror()); return nullptr; }
+  auto sym = [&](const char* n) { return dlsym(h, n); };
+  api.GetUniqueId = (int (*)(NcclId*))sym("ncclGetUniqueId");
+  api.CommInitRank = (int (*)(void**, int, NcclId, int))sym("ncclCommInitRank");
+  api.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+  api.CommCount = (int (*)(void*, int*))sym("ncclCommCount");
+  api.CommUserRank = (int (*)(void*, int*))sym("ncclCommUserRank");
+  api.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclAllReduce");
+  api.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclBroadcast");
+  api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+  api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.CommCount && api.CommUserRank && api.AllReduce &&
+           api.Broadcast;
+  if (!api.ok) dg_set_error("RCCL: librccl.so lacks one of the entry points this binding needs");
+  return api.ok ? &api : nullptr;
+}
+int rccl_check(RcclApi* a, int rc, const char* what) {
+  if (rc == 0) return DG_OK;
+  dg_set_error("RCCL: %s failed: %s", what, a->GetErrorString ? a->GetErrorString(rc) : "?");
+  return DG_ERR_HIP;
+}
+}  // namespace
+
 static int dp_reduce(depgan_ctx* c, float* dev, long n) {
+  if (c->rccl_comm) {
+    ProfScope ps(c, 2, 0.0, "all-reduce");
+    RcclApi* a = rccl_api();
+    if (!a) return DG_ERR_HIP;
+    c->rccl_issued += 1;
+    return rccl_check(a, a->AllReduce(dev, dev, (size_t)n, kNcclFloat, kNcclSum, c->rccl_comm, c->st), "ncclAllReduce");
+  }
   if (!c->ar_fn) return DG_OK;
   ProfScope ps(c, 2, 0.0, "all-reduce");
   const int rc = c->ar_fn(c->ar_user, dev, n, (void*)c->st);
@@ -1144,7 +1206,7 @@ static int finish_update(depgan_ctx* c, int net, Net& n, int nstats, int slot_fl
   if (update) DGCHECK(dp_reduce(c, n.G, (long)n.nTrain + STATS_TAIL));
   DGCHECK(fetch_async(c, n.G + n.nTrain, nstats, slot_floats));
   if (!update) return DG_OK;
-  DGCHECK(net_adam(c, n, c->ar_fn ? 1.0f / (float)c->world : 1.0f));
+  DGCHECK(net_adam(c, n, (c->ar_fn || c->rccl_comm) ? 1.0f / (float)c->world : 1.0f));
   return refresh_net(c, net);
 }
 
@@ -1214,6 +1276,7 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
   }
   depgan_ctx* c = new depgan_ctx();
   c->cfg = *cfg;
+  if (hipGetDevice(&c->device) != hipSuccess) c->device = 0;
   if (c->cfg.nc_out <= 0) c->cfg.nc_out = 1;
   if (c->cfg.nc_out != 1 && c->cfg.nc_out != 4) {
     dg_set_error("depgan_create: nc_out must be 1 (DEP-GAN) or 4 (DEP-UResNet)");
@@ -1280,6 +1343,7 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
 void depgan_destroy(depgan_ctx* c) {
   if (!c) return;
   hipDeviceSynchronize();
+  depgan_rccl_shutdown(c);
   for (void* p : c->allocs) hipFree(p);
   if (c->host_stats) hipHostFree(c->host_stats);
   for (ProfRec& r : c->recs) {
@@ -1294,7 +1358,76 @@ int depgan_set_stream(depgan_ctx* c, void* s) {
   return DG_OK;
 }
 
+int depgan_rccl_unique_id(void* id_out) {
+  RcclApi* a = rccl_api();
+  if (!a || !id_out) { if (a) dg_set_error("rccl_unique_id: null argument"); return a ? DG_ERR_ARG : DG_ERR_HIP; }
+  NcclId id;
+  DGCHECK(rccl_check(a, a->GetUniqueId(&id), "ncclGetUniqueId"));
+  memcpy(id_out, &id, sizeof(id));
+  return DG_OK;
+}
+
+int depgan_rccl_shutdown(depgan_ctx* c) {
+  if (!c || !c->rccl_comm) return DG_OK;
+  RcclApi* a = rccl_api();
+  hipStreamSynchronize(c->st);
+  if (a) a->CommDestroy(c->rccl_comm);
+  c->rccl_comm = nullptr;
+  c->world = c->ar_fn ? c->world : 1;
+  return DG_OK;
+}
+
+int depgan_rccl_init(depgan_ctx* c, const void* id, int rank, int world) {
+  if (!c || !id || world < 1 || rank < 0 || rank >= world) { dg_set_error("rccl_init: need 0 <= rank < world and an id"); return DG_ERR_ARG; }
+  // The loss pieces travel as float32 in the tail of the gradient all-reduce; the voxel counts among them (sum wr, sum
+  // wf, sum wr*wf, GT:581-589) are exact only up to 2^24 per GLOBAL batch
+  if ((double)world * c->cfg.batch * c->cfg.height * c->cfg.width > 16777216.0) {
+    dg_set_error("rccl_init: world x batch x H x W = %.0f exceeds 2^24: the float32 voxel counts of the global batch "
+                 "(M3 / M4, GT:581-589) would round", (double)world * c->cfg.batch * c->cfg.height * c->cfg.width);
+    return DG_ERR_ARG;
+  }
+  RcclApi* a = rccl_api();
+  if (!a) return DG_ERR_HIP;
+  depgan_rccl_shutdown(c);
+  HIPCHECK(hipSetDevice(c->device));
+  NcclId nid;
+  memcpy(&nid, id, sizeof(nid));
+  void* comm = nullptr;
+  DGCHECK(rccl_check(a, a->CommInitRank(&comm, world, nid, rank), "ncclCommInitRank"));
+  c->rccl_comm = comm;
+  c->rccl_issued = 0;
+  c->world = world;
+  c->ar_fn = nullptr;
+  c->ar_user = nullptr;
+  return DG_OK;
+}
+
+int depgan_rccl_broadcast(depgan_ctx* c, float* dev, long n, int root) {
+  if (!c || !c->rccl_comm) { dg_set_error("rccl_broadcast: no communicator (depgan_rccl_init)"); return DG_ERR_ARG; }
+  if (n <= 0) return DG_OK;
+  RcclApi* a = rccl_api();
+  return rccl_check(a, a->Broadcast(dev, dev, (size_t)n, kNcclFloat, root, c->rccl_comm, c->st), "ncclBroadcast");
+}
+
+int depgan_rccl_info(depgan_ctx* c, int* nranks, int* rank, long* issued) {
+  if (!c || !c->rccl_comm) { dg_set_error("rccl_info: no communicator (depgan_rccl_init)"); return DG_ERR_ARG; }
+  RcclApi* a = rccl_api();
+  int n = 0, r = -1;
+  DGCHECK(rccl_check(a, a->CommCount(c->rccl_comm, &n), "ncclCommCount"));
+  DGCHECK(rccl_check(a, a->CommUserRank(c->rccl_comm, &r), "ncclCommUserRank"));
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+  if (issued) *issued = c->rccl_issued;
+  return DG_OK;
+}
+
 int depgan_set_allreduce(depgan_ctx* c, depgan_allreduce_fn fn, void* user, int world) {
+  if (fn && (double)world * c->cfg.batch * c->cfg.height * c->cfg.width > 16777216.0) {
+    dg_set_error("set_allreduce: world x batch x H x W = %.0f exceeds 2^24: the float32 voxel counts of the global batch "
+                 "(M3 / M4, GT:581-589) would round", (double)world * c->cfg.batch * c->cfg.height * c->cfg.width);
+    return DG_ERR_ARG;
+  }
+  if (fn && c->rccl_comm) depgan_rccl_shutdown(c);
   if (fn && world >= 1) {   // world == 1 keeps the hook (a one-rank group: rehearses the collective path exactly)
     c->ar_fn = fn;
     c->ar_user = user;
@@ -1525,11 +1658,12 @@ int depgan_profile_dump(depgan_ctx* c, const char* path) {
   HIPCHECK(hipStreamSynchronize(c->st));
   FILE* f = fopen(path, "w");
   if (!f) { dg_set_error("cannot open %s", path); return DG_ERR_ARG; }
-  fprintf(f, "class,label,ms,gflop\n");
+  fprintf(f, "class,label,ms,gflop,mbytes,kernel\n");
   for (ProfRec& r : c->recs) {
     float t = 0;
     hipEventElapsedTime(&t, r.a, r.b);
-    fprintf(f, "%d,%s,%.4f,%.3f\n", r.klass, r.label, t, r.flops * 1e-9);
+    // the kernel name holds commas (template arguments): quoted
+    fprintf(f, "%d,%s,%.4f,%.3f,%.3f,\"%s\"\n", r.klass, r.label, t, r.flops * 1e-9, r.bytes * 1e-6, r.kernel);
   }
   fclose(f);
   return DG_OK;

@@ -389,11 +389,10 @@ template <int MF, int KS, int TPW, int TH>
 static int launch_wgrad_dma(WgradArgs a, int nchunks, int gridY, hipStream_t st) {
   constexpr size_t lds = WDmaCfg<MF, KS, TPW, TH>::LDS_BYTES;
   static_assert(lds <= 160 * 1024, "two tile buffers must fit the CU's LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DgOncePerDevice once;
+  if (once.need()) {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<MF, KS, TPW, TH>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   hipLaunchKernelGGL((wgrad_dma_kernel<MF, KS, TPW, TH>), dim3(nchunks, gridY), dim3(256), lds, st, a);
   HIPCHECK(hipGetLastError());

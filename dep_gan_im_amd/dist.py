@@ -1,12 +1,18 @@
 """Batch-sharded data parallelism for the train step.
 
 The reference is single-GPU (GT:13).  Here every rank holds full replicas of G
-and both critics and a shard of the batch.  libdepgan stays free of any
-communication dependency: it calls ONE hook (depgan_set_allreduce) that
-all-reduces device floats in place, enqueued on the engine's HIP stream; this
-module implements that hook with torch.distributed (RCCL over xGMI when the
-process group backend is "nccl"; gloo on CPU in the tests).  Per network update
-there is exactly one collective: the flat fp32 gradient arena with the
+and both critics and a shard of the batch.  On GPUs the library talks to RCCL
+itself (include/depgan.h, depgan_rccl_*): this module only hands rank 0's
+ncclUniqueId to the other ranks (one torch.distributed broadcast of 128 bytes,
+any backend) and asks the library to broadcast rank 0's weights; from then on
+every update's collective is an ncclAllReduce the library enqueues on its own
+stream -- no Python, no GIL on the data path.  The hook form
+(depgan_set_allreduce, implemented here with torch.distributed) remains for
+host memory (gloo: CPU tests with an engine double) and for two ranks sharing
+one GPU (tests / DEPGAN_BENCH_ONE_GPU rehearsal, where RCCL refuses to run),
+and must be asked for explicitly when the engine is on a GPU (host_staging=True):
+it synchronises the stream on every collective.  Per network update there is
+exactly one collective: the flat fp32 gradient arena with the
 update's un-normalised loss pieces riding in its tail, summed; Adam divides the
 gradient by the world size (losses are batch means, GT:540-545, 576), and every
 rank forms the same GLOBAL scalars from the summed pieces -- M3/M4 (GT:583-589)
@@ -54,16 +60,33 @@ def combine_generator_sums(s):
 
 
 class DataParallel:
-    def __init__(self, group=None):
+    def __init__(self, group=None, host_staging=False, direct_rccl=True):
+        """host_staging: allow a GPU engine under a group whose collectives run on host memory (gloo): every message is
+        copied through the host and the stream is synchronised -- tests and rehearsals only.
+        direct_rccl: GPU engines use the library's own RCCL communicator (the default); False keeps the
+        torch.distributed hook on an "nccl" group (the round-2 path, kept for comparison)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised before building DataParallel")
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.on_device = dist.get_backend(group) == "nccl"
+        backend = str(dist.get_backend(group))
+        # a composite backend ("cpu:gloo,cuda:nccl") serves device tensors through its nccl part
+        self.on_device = "nccl" in backend
+        self.host_staging = bool(host_staging)
+        self.direct_rccl = bool(direct_rccl)
+        self.direct = False      # set by attach(): the engine reduces through its own RCCL communicator
         self._views = {}
         self.device = None
-        self.calls = 0          # collectives issued (tests / bench report it)
+        self.engine = None
+        self._calls = 0          # collectives issued through the hook (tests / bench report `calls`)
+
+    @property
+    def calls(self):
+        """Collectives issued so far: by the library's RCCL communicator (as it counts them) or through the hook."""
+        if self.direct and self.engine is not None:
+            return self.engine.rccl_info()[2]
+        return self._calls
 
     # ---- the hook: in-place summing all-reduce of n floats at a raw pointer ----
     def _view(self, ptr, n):
@@ -78,7 +101,7 @@ class DataParallel:
         return t
 
     def allreduce_ptr(self, ptr, n, stream=0):
-        self.calls += 1
+        self._calls += 1
         if not self.on_device and self.device is not None and getattr(self.device, "type", "cpu") == "cuda":
             # gloo group around GPU engines (tests: two ranks sharing one GPU, where RCCL refuses to run): the message is
             # staged through the host.  Synchronises the stream -- a test path, not the product's.
@@ -106,6 +129,14 @@ class DataParallel:
         state replace every other rank's (replicas built from different seeds would otherwise apply the averaged
         gradient to different models and never agree), then the all-reduce hook is registered."""
         self.device = getattr(engine, "device", None)
+        self.engine = engine
+        on_gpu = getattr(self.device, "type", "cpu") == "cuda"
+        if on_gpu and self.direct_rccl and not self.host_staging:
+            return self._attach_direct(engine, nets)
+        if on_gpu and not self.on_device and not self.host_staging:
+            raise RuntimeError("a GPU engine under a %r process group would stage every collective through the host and "
+                               "synchronise the stream: build DataParallel(host_staging=True) if that is what you want "
+                               "(tests / one-GPU rehearsals), or leave direct_rccl on" % str(dist.get_backend(self.group)))
         for net in nets:
             for arena in (ARENA_PARAMS, ARENA_NONTRAINABLE, ARENA_ADAM_M, ARENA_ADAM_V):
                 ptr, n = engine.arena(net, arena)
@@ -117,6 +148,41 @@ class DataParallel:
             engine.adam_step(net, int(t.item()))
             engine.weights_changed(net)
         engine.set_allreduce(self.allreduce_ptr, self.world)
+        return engine
+
+    def _attach_direct(self, engine, nets):
+        """The product path: the library's own RCCL communicator.  torch.distributed carries the 128-byte id only."""
+        box = [engine.rccl_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=self._global_rank0(), group=self.group)
+        # RCCL prints a version banner on file descriptor 1 when a communicator is created; callers (bench.py) own stdout
+        # for their result line, so the banner is sent to stderr
+        import os
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            engine.rccl_init(box[0], self.rank, self.world)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        nranks, rank, _ = engine.rccl_info()
+        if (nranks, rank) != (self.world, self.rank):
+            raise RuntimeError("RCCL reports rank %d of %d, the process group says %d of %d" % (rank, nranks, self.rank,
+                                                                                                self.world))
+        steps = []
+        for net in nets:
+            for arena in (ARENA_PARAMS, ARENA_NONTRAINABLE, ARENA_ADAM_M, ARENA_ADAM_V):
+                ptr, n = engine.arena(net, arena)
+                if n:
+                    engine.rccl_broadcast(ptr, n, 0)
+            steps.append(engine.adam_step(net))
+        box = [steps if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=self._global_rank0(), group=self.group)
+        for net, t in zip(nets, box[0]):
+            engine.adam_step(net, int(t))
+            engine.weights_changed(net)
+        self.direct = True
         return engine
 
     def _broadcast_ptr(self, ptr, n):

@@ -207,6 +207,36 @@ class Engine:
         self.world = int(world)
         check(self.lib.depgan_set_allreduce(self.h, self._ar_cb, None, int(world)), "depgan_set_allreduce")
 
+    # ---- direct RCCL binding (include/depgan.h): the library calls ncclAllReduce itself ----
+    def rccl_unique_id(self):
+        """The 128-byte ncclUniqueId (rank 0 creates it; the host hands it to every rank)."""
+        buf = C.create_string_buffer(_lib.RCCL_ID_BYTES)
+        check(self.lib.depgan_rccl_unique_id(buf), "depgan_rccl_unique_id")
+        return buf.raw
+
+    def rccl_init(self, uid, rank, world):
+        """Collective: ncclCommInitRank on this engine's device.  Every update then all-reduces inside the library."""
+        if len(uid) != _lib.RCCL_ID_BYTES:
+            raise ValueError("an ncclUniqueId is %d bytes" % _lib.RCCL_ID_BYTES)
+        _torch().cuda.set_device(self.device)
+        self._ar_cb = None
+        check(self.lib.depgan_rccl_init(self.h, C.c_char_p(uid), int(rank), int(world)), "depgan_rccl_init")
+        self.world = int(world)
+
+    def rccl_broadcast(self, ptr, n, root=0):
+        self._use_current_stream()
+        check(self.lib.depgan_rccl_broadcast(self.h, C.c_void_p(ptr), int(n), int(root)), "depgan_rccl_broadcast")
+
+    def rccl_info(self):
+        """(nranks, rank) as RCCL reports them, collectives issued by this engine."""
+        n, r, k = C.c_int(), C.c_int(), C.c_long()
+        check(self.lib.depgan_rccl_info(self.h, C.byref(n), C.byref(r), C.byref(k)), "depgan_rccl_info")
+        return n.value, r.value, k.value
+
+    def rccl_shutdown(self):
+        check(self.lib.depgan_rccl_shutdown(self.h), "depgan_rccl_shutdown")
+        self.world = 1 if self._ar_cb is None else self.world
+
     def _check(self, rc, what):
         err = getattr(self, "_ar_err", None)
         if err is not None:

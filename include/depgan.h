@@ -79,6 +79,27 @@ int depgan_set_stream(depgan_ctx* ctx, void* hip_stream);
 typedef int (*depgan_allreduce_fn)(void* user, float* dev_ptr, long n, void* hip_stream);
 int depgan_set_allreduce(depgan_ctx* ctx, depgan_allreduce_fn fn, void* user, int world);
 
+/* Direct RCCL binding ("ncclAllReduce ... one call per network per step").  The library calls
+ * ncclAllReduce(arena, nTrain + 8, ncclFloat, ncclSum, comm, stream) itself, on the context's stream, for every network
+ * update (and once per best-of-k evaluation block); librccl is resolved at run time -- the copy already loaded in the
+ * process (PyTorch-ROCm ships one), else dlopen("librccl.so.1") -- so libdepgan.so has no link dependency on it.
+ *   depgan_rccl_unique_id:  rank 0 creates the 128-byte ncclUniqueId; the host hands it to every rank by any means
+ *                           (dep_gan_im_amd/dist.py: one torch.distributed broadcast of the bytes).
+ *   depgan_rccl_init:       collective over all ranks: ncclCommInitRank on the context's device.  Replaces a hook
+ *                           registered with depgan_set_allreduce; from then on the closures behave as described there
+ *                           (global scalars, gradients divided by `world` inside Adam).  world = 1 is a one-rank job.
+ *   depgan_rccl_broadcast:  ncclBroadcast of n device floats from `root`, enqueued on the context's stream (replica
+ *                           initialisation: rank 0's weights, BN statistics and Adam state).
+ *   depgan_rccl_info:       communicator size and rank as RCCL reports them (ncclCommCount / ncclCommUserRank) and
+ *                           the number of collectives this context has issued.
+ *   depgan_rccl_shutdown:   ncclCommDestroy (depgan_destroy does it as well). */
+#define DEPGAN_RCCL_ID_BYTES 128
+int depgan_rccl_unique_id(void* id_out);
+int depgan_rccl_init(depgan_ctx* ctx, const void* id, int rank, int world);
+int depgan_rccl_broadcast(depgan_ctx* ctx, float* dev_ptr, long n, int root);
+int depgan_rccl_info(depgan_ctx* ctx, int* nranks, int* rank, long* collectives_issued);
+int depgan_rccl_shutdown(depgan_ctx* ctx);
+
 /* model.trainable_weights / get_weights / set_weights (GT:549, 892; GE:383) */
 int depgan_param_count(depgan_ctx* ctx, int net);
 int depgan_param_info(depgan_ctx* ctx, int net, int index, char* name, int name_cap, int shape[4], int* ndim,
@@ -161,7 +182,8 @@ int depgan_profile_read(depgan_ctx* ctx, int klass, double* total_ms, long* laun
 /* sum over the class's recorded launches of the algorithmic HBM bytes (operands once, results once; class 0 only) */
 int depgan_profile_read_bytes(depgan_ctx* ctx, int klass, double* bytes);
 int depgan_profile_reset(depgan_ctx* ctx);
-/* one CSV row per recorded launch: class,label,ms,gflop */
+/* one CSV row per recorded launch: class,label,ms,gflop,mbytes,kernel (algorithmic GFLOP / MB of the launch; kernel =
+ * the template instantiation as rocprofv3 names it, for the MFMA convolution class) */
 int depgan_profile_dump(depgan_ctx* ctx, const char* path);
 
 /* ---- evaluation step after the path (DEP-GAN_testing_4fold.py "GE":616-807) ----

@@ -185,8 +185,9 @@ def test_data_parallel_property_on_one_gpu(lib):
 
 
 def test_rccl_path_world1_matches_single_process(lib):
-    """The data-parallel closures (grad arena aliased as a torch tensor, RCCL all-reduce, global-sum
-    scalars) on a 1-rank 'nccl' group must reproduce the plain closures exactly."""
+    """The data-parallel closures on a 1-rank group must reproduce the plain closures exactly, both ways the collective
+    can be issued: by the library itself (depgan_rccl_init: ncclAllReduce from C on the engine's stream -- the product
+    path; RCCL must report 1 rank) and through the torch.distributed hook on the "nccl" group (the round-2 path)."""
     import socket
     import torch.distributed as dist
     import dep_gan_im_amd as dg
@@ -203,11 +204,14 @@ def test_rccl_path_world1_matches_single_process(lib):
         img, B = 64, 2
         PG, PD1, PD2, x, y2, z, ep = _setup(img, B, 61, noisy=True)
         outs, weights = [], []
-        for use_dist in (False, True):
+        for mode in ("none", "direct", "hook"):
             nets = [dg.Gen_UNet2D((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1)), dg.Dis_C2D_FCN1((img, img, 1))]
             for n, P in zip(nets, (PG, PD1, PD2)):
                 n.set_weights({k: v.copy() for k, v in P.items()})
-            tr = dg.build_trainers(*nets, batchSize=B, dist=DataParallel() if use_dist else None)
+            dp = None if mode == "none" else DataParallel(direct_rccl=(mode == "direct"))
+            tr = dg.build_trainers(*nets, batchSize=B, dist=dp)
+            if mode == "direct":
+                assert dp.direct and tr.engine.rccl_info()[:2] == (1, 0)       # RCCL's own count and rank
             o = tr.netD_y2_train([y2, x, z, ep]) + tr.netD_dem_train([y2, x, z, ep]) + tr.netG_no_update([x, y2, z]) \
                 + tr.netG_train([x, y2, z])
             # ... and the one-call generator iteration, whose 4 collectives (2 critic updates, the k x 8 loss pieces of
@@ -216,14 +220,16 @@ def test_rccl_path_world1_matches_single_process(lib):
             cy, cd, ev, g6, best = tr.gen_iteration((x, y2, z[None], ep[None], 1), (x, y2, z[None], ep[None], 1),
                                                     (x, y2, zs))
             o = o + cy[0] + cd[0] + [v for e in ev for v in e] + g6 + [float(best)]
-            if use_dist:
+            if dp is not None:
                 assert tr.dist.calls == 4 + 4               # closures: 3 updates + 1 evaluation; then the iteration's 4
             outs.append(o)
             weights.append([n.get_weights_dict() for n in nets])
-        np.testing.assert_allclose(outs[0], outs[1], rtol=2e-6, atol=1e-7)
-        for wa, wb in zip(weights[0], weights[1]):
-            for k in wa:
-                np.testing.assert_array_equal(wa[k], wb[k])
+            tr.engine.close()
+        for k in (1, 2):
+            np.testing.assert_allclose(outs[0], outs[k], rtol=2e-6, atol=1e-7)
+            for wa, wb in zip(weights[0], weights[k]):
+                for kk in wa:
+                    np.testing.assert_array_equal(wa[kk], wb[kk])
     finally:
         dist.destroy_process_group()
 
@@ -531,13 +537,18 @@ def test_other_generator_widths_fail_loudly(lib):
         Engine(2, 64, 64, 1, first_fm=16)
 
 
-def _dp_rank(rank, world, port, q, payload):
-    """One data-parallel rank with a REAL engine (gloo group: two ranks may share one GPU, RCCL may not)."""
+def _dp_rank(rank, world, port, q, payload, own_gpu=False):
+    """One data-parallel rank with a REAL engine.  own_gpu = False: both ranks share cuda:0 under a gloo group with host
+    staging (RCCL refuses two ranks on one device).  own_gpu = True: rank r on cuda:r, the library's own RCCL
+    communicator -- the product path (the group only carries the 128-byte id)."""
     import torch.distributed as dist
     import dep_gan_im_amd as dg
     from dep_gan_im_amd.dist import DataParallel
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if own_gpu:
+        torch.cuda.set_device(rank)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         img, B, P, x, y2, z, ep, zs = payload
@@ -548,7 +559,10 @@ def _dp_rank(rank, world, port, q, payload):
         if rank == 0:
             for n, Pn in zip(nets, P):
                 n.set_weights(Pn)
-        tr = dg.build_trainers(*nets, batchSize=B, dist=DataParallel())
+        tr = dg.build_trainers(*nets, batchSize=B, dist=DataParallel(host_staging=not own_gpu))
+        assert tr.dist.direct == own_gpu
+        if own_gpu:
+            assert tr.engine.rccl_info()[:2] == (world, rank)
         xs, ys, zz, ee = x[lo:hi], y2[lo:hi], z[lo:hi], ep[lo:hi]
         outs = tr.netD_y2_train([ys, xs, zz, ee]) + tr.netD_dem_train([ys, xs, zz, ee]) + tr.netG_no_update([xs, ys, zz]) \
             + tr.netG_train([xs, ys, zz])
@@ -560,14 +574,19 @@ def _dp_rank(rank, world, port, q, payload):
         dist.destroy_process_group()
 
 
-def test_two_real_ranks_equal_one_process_on_the_global_batch(lib):
-    """Data parallelism end to end with two REAL engines (two processes sharing this GPU, gloo instead of RCCL, the
-    library's hook protocol unchanged): replicas built from different seeds are made identical by attach(), every
-    closure and the one-call generator iteration report the GLOBAL scalars on both ranks, the replicas stay bitwise
-    identical through four updates each, and all of it equals ONE process fed the global batch."""
+@pytest.mark.parametrize("own_gpu", [False, True], ids=["one_gpu_gloo_staging", "two_gpus_rccl"])
+def test_two_real_ranks_equal_one_process_on_the_global_batch(lib, own_gpu):
+    """Data parallelism end to end with two REAL engines: replicas built from different seeds are made identical by
+    attach(), every closure and the one-call generator iteration report the GLOBAL scalars on both ranks, the replicas
+    stay bitwise identical through four updates each, and all of it equals ONE process fed the global batch.
+    one_gpu_gloo_staging: two processes sharing this GPU, the library's hook protocol with the messages staged through
+    the host (RCCL refuses two ranks on one device).  two_gpus_rccl: one rank per GPU over the library's own RCCL
+    communicator (ncclAllReduce issued from C) -- runs wherever two devices are visible, skipped on a one-GPU box."""
     import socket
     import torch.multiprocessing as mp
     import dep_gan_im_amd as dg
+    if own_gpu and torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU node); one visible here")
     img, B, world = 64, 2, 2
     PG, PD1, PD2, x, y2, z, ep = _setup(img, B * world, 71, noisy=True)
     zs = np.random.default_rng(3).normal(size=(3, B * world, 32, 1)).astype(np.float32)
@@ -578,7 +597,7 @@ def test_two_real_ranks_equal_one_process_on_the_global_batch(lib):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     payload = (img, B, (PG, PD1, PD2), x, y2, z, ep, zs)
-    procs = [ctx.Process(target=_dp_rank, args=(r, world, port, q, payload)) for r in range(world)]
+    procs = [ctx.Process(target=_dp_rank, args=(r, world, port, q, payload, own_gpu)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])

@@ -56,6 +56,9 @@ def main():
         "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in cls) / max(n, 1),
         "read_bytes_per_launch": sum((v["read_bytes_per_launch"] or 0) * v["launches"] for v in cls) / max(n, 1),
         "write_bytes_per_launch": sum((v["write_bytes_per_launch"] or 0) * v["launches"] for v in cls) / max(n, 1)},
+        # set by tools/collect_profiles.sh: the passes wrapped `DEPGAN_BENCH_STEP_ONLY=1 bench.py` (canonical steps only), so
+        # `launches` is steps x launches-per-step and bench.py can check that it divides
+        "step_only": bool(os.environ.get("DEPGAN_BENCH_STEP_ONLY")),
         "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE KiB x1024",
         "kernels": rows}
     with open(out, "w") as fh:
