@@ -231,6 +231,10 @@ int dg_pack_weights(const ConvPlan& pl, const float* src, int srcI, int srcO, in
                     const float* kscale, float* dst, hipStream_t st);
 
 int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
+// wave-private 3x3 kernel (igemm_wp.hip): no workgroup barrier in steady state; reads the 8-channel-chunk plan's panel
+bool dg_conv_igemm_wp_supported(const ConvPlan& pl, const ConvArgs& a, bool force);
+int dg_conv_igemm_wp(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
+int dg_conv_igemm_tile(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
 // name of the kernel instantiation dg_conv_igemm launches for (pl, a), as rocprofv3 prints it
 void dg_conv_igemm_name(const ConvPlan& pl, const ConvArgs& a, char* buf, size_t cap);
 int dg_conv_direct(int KS, const ConvArgs& a, hipStream_t st);

@@ -474,10 +474,11 @@ void dg_conv_igemm_name(const ConvPlan& pl, const ConvArgs& a, char* buf, size_t
   if (cap) buf[0] = 0;
   if (pl.variant < 0) { snprintf(buf, cap, "conv_direct"); return; }
   if (pl.bf16) { snprintf(buf, cap, pl.variant >= 200 ? "igemm_split_kernel" : "igemm_bf16_kernel"); return; }
+  if (dg_conv_igemm_wp_supported(pl, a, false)) { snprintf(buf, cap, "igemm_wp_kernel<0>"); return; }
   dispatch_variant(pl, a, nullptr, buf, cap);
 }
 
-int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
+static int conv_igemm_impl(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st, bool allow_wp) {
   ConvArgs a = a_in;
   const bool is_bf16 = pl.bf16 != 0;
   if (pl.variant < 0) {
@@ -506,8 +507,13 @@ int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
     }
   }
   if (is_bf16) return dg_conv_igemm_bf16(pl, a, st);
+  if (allow_wp && dg_conv_igemm_wp_supported(pl, a, false)) return dg_conv_igemm_wp(pl, a, st);
   return dispatch_variant(pl, a, st, nullptr, 0);
 }
+
+int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a, hipStream_t st) { return conv_igemm_impl(pl, a, st, true); }
+// the workgroup-tile kernels only (unit tests: the reference the wave-private kernel must match bit for bit)
+int dg_conv_igemm_tile(const ConvPlan& pl, const ConvArgs& a, hipStream_t st) { return conv_igemm_impl(pl, a, st, false); }
 
 // ---------------------------------------------------------------------------
 // weight packing:  dst[nt][cc][tap][n][k]

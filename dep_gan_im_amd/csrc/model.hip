@@ -1760,7 +1760,8 @@ static int op_conv(const float* in, const float* w_hwio, const float* bias, floa
   ConvPlan pl = (path == 3) ? dg_plan_conv_bf16(KS, ci, co)
                 : (path == 4 || path == 5) ? dg_plan_conv_split(KS, ci, co, path == 5 ? 3 : 2)
                 : (path == 6) ? dg_plan_conv_items(KS, ci, co, 1L << 30) : dg_plan_conv(KS, ci, co);
-  if (path == 6 && pl.CK != 8) { dg_set_error("op_conv: the 8-channel-chunk variant does not cover this shape"); return DG_ERR_UNSUPPORTED; }
+  if (path == 7) pl = dg_plan_conv_items(KS, ci, co, 1L << 30);
+  if ((path == 6 || path == 7) && pl.CK != 8) { dg_set_error("op_conv: the 8-channel-chunk variant does not cover this shape"); return DG_ERR_UNSUPPORTED; }
   if (path >= 3 && path <= 5 && !pl.bf16) { dg_set_error("op_conv: the bf16 MFMA kernel does not cover this shape"); return DG_ERR_UNSUPPORTED; }
   if (path == 1 && pl.variant < 0) { dg_set_error("op_conv: MFMA path not available for this shape"); return DG_ERR_UNSUPPORTED; }
   if (path != 2 && pl.variant >= 0) {
@@ -1769,7 +1770,15 @@ static int op_conv(const float* in, const float* w_hwio, const float* bias, floa
     int rc = dg_pack_weights(pl, w_hwio, Cin, Cout, 0, bwd, bwd, nullptr, wp, st);
     if (rc == DG_OK) {
       a.w = wp;
-      rc = dg_conv_igemm(pl, a, st);
+      if (path == 7) {
+        if (dg_conv_igemm_wp_supported(pl, a, true)) rc = dg_conv_igemm_wp(pl, a, st);
+        else { dg_set_error("op_conv: the wave-private kernel does not cover this shape"); rc = DG_ERR_UNSUPPORTED; }
+      } else if (path == 6) {
+        // the workgroup-tile kernel itself (the reference the wave-private kernel must match bit for bit)
+        rc = dg_conv_igemm_tile(pl, a, st);
+      } else {
+        rc = dg_conv_igemm(pl, a, st);
+      }
     }
     hipStreamSynchronize(st);
     hipFree(wp);

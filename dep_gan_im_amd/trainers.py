@@ -67,9 +67,10 @@ class Trainers:
         return self.engine.gen_iteration(y2_loop, dem_loop, gen, batch_stride)
 
     # ---- training state: the three networks, their optimisers and the schedule counters (GT:47-50, 892) ----
-    def state_dict(self, schedule_state=None):
+    def state_dict(self, schedule_state=None, extra=None):
         """Everything a resumed run needs to continue bit-identically: weights and BN moving statistics by their
-        Keras names, Adam m / v arenas and `iterations` per optimiser, and the reference's module-level counters."""
+        Keras names, Adam m / v arenas and `iterations` per optimiser, and the reference's module-level counters.
+        extra: dict of arrays the DRIVER needs for the same guarantee (its RNG state, the data order, the epoch)."""
         from ._lib import ARENA_ADAM_M, ARENA_ADAM_V
         out = {}
         for net in ("G", "D_y2", "D_dem"):
@@ -82,10 +83,24 @@ class Trainers:
             for k in ("gen_iterations", "crit_iterations", "crit_dem_iterations"):
                 out["schedule/" + k] = np.asarray(getattr(schedule_state, k), np.int64)
             out["schedule/errG"] = np.asarray(schedule_state.errG, np.float64)
+        for k, v in (extra or {}).items():
+            out["extra/" + k] = np.asarray(v)
         return out
 
-    def save_state(self, path, schedule_state=None):
-        np.savez(path, **self.state_dict(schedule_state))
+    def save_state(self, path, schedule_state=None, extra=None):
+        np.savez(path, **self.state_dict(schedule_state, extra))
+
+    @staticmethod
+    def rng_to_arrays(rng):
+        """np.random.RandomState -> dict of arrays for `extra` (and back: rng_from_arrays)."""
+        name, keys, pos, has_gauss, cached = rng.get_state()
+        return {"rng_keys": keys, "rng_pos": np.asarray([pos, has_gauss], np.int64), "rng_gauss": np.asarray(cached)}
+
+    @staticmethod
+    def rng_from_arrays(rng, extra):
+        rng.set_state(("MT19937", np.asarray(extra["rng_keys"], np.uint32), int(extra["rng_pos"][0]),
+                       int(extra["rng_pos"][1]), float(extra["rng_gauss"])))
+        return rng
 
     def load_state(self, path_or_dict, schedule_state=None):
         from ._lib import ARENA_ADAM_M, ARENA_ADAM_V
@@ -109,6 +124,7 @@ class Trainers:
             for k in ("gen_iterations", "crit_iterations", "crit_dem_iterations"):
                 setattr(schedule_state, k, int(d["schedule/" + k]))
             schedule_state.errG = float(d["schedule/errG"])
+        self.extra = {k[len("extra/"):]: v for k, v in d.items() if k.startswith("extra/")}
         return schedule_state
 
     # train_on_batch-style aliases

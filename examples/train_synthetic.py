@@ -10,7 +10,9 @@ iterations, best-of-10 noise, one generator update), log, validate with predict,
 
 The training set is moved to HBM once (a 288-GB device holds any realistic set of 256x256 slices), every generator
 iteration is one library call with one host synchronisation (depgan_gen_iteration), the full training state is
-checkpointed each epoch and --resume continues bit-identically.
+checkpointed each epoch -- networks, Adam state, schedule counters AND the driver's own state: the RNG, the cumulative
+data order (the reference reshuffles the already shuffled arrays, GT:783-787) and the epoch -- so --resume continues the
+uninterrupted run bit for bit.  Every rank reads the state file rank 0 wrote: one node / a shared filesystem.
 """
 import argparse
 import os
@@ -79,10 +81,16 @@ def main():
 
     state = ScheduleState()
     state.gen_iterations = 26          # skip the 100-iteration critic warm-up of the first 25 iterations (GT:795)
+    rng = np.random.RandomState(1234)                             # identical on every rank: draws are for the GLOBAL batch
+    order = np.arange(train_1tp.shape[0])                          # cumulative permutation of the training set
+    first_epoch = 0
     if args.resume and os.path.exists(args.state):
         t.load_state(args.state, state)
-        print("resumed at generator iteration", state.gen_iterations)
-    rng = np.random.RandomState(1234 + state.gen_iterations)      # identical on every rank: draws are for the GLOBAL batch
+        t.rng_from_arrays(rng, t.extra)
+        order, first_epoch = np.asarray(t.extra["order"]), int(t.extra["epoch"]) + 1
+        idx = torch.from_numpy(order).cuda()
+        train_1tp, train_2tp = train_1tp[idx], train_2tp[idx]
+        print("resumed after epoch %d at generator iteration %d" % (first_epoch, state.gen_iterations))
 
     def log(r):
         if rank != 0:
@@ -92,10 +100,15 @@ def main():
                                  r["errG_CY2"], r["errG_DEM"], r["errG_MSE"], r["errG_VOL"], r["errG_WMH"], r["best_noise"]),
               flush=True)
 
-    for epoch in range(args.epochs):
+    for epoch in range(first_epoch, first_epoch + args.epochs):
         t0 = time.time()
+        indices = np.arange(train_1tp.shape[0])                    # GT:783-787: reshuffle the (already shuffled) arrays
+        rng.shuffle(indices)
+        order = order[indices]
+        idx = torch.from_numpy(indices).cuda()
+        train_1tp, train_2tp = train_1tp[idx], train_2tp[idx]
         train_epoch(t, train_1tp, train_2tp, batchSize=args.batch, Diters=5, state=state, on_gen_iteration=log, rng=rng,
-                    rank=rank, world=world)
+                    rank=rank, world=world, shuffle=False)
         fake_dem = netG.predict([val_1tp, fixed_noise])                                            # GT:846-859
         val_real = float(netD_y2.predict(val_2tp).mean())
         val_fake = float(netD_y2.predict(val_1tp[..., 0:1] + fake_dem).mean())
@@ -103,7 +116,7 @@ def main():
               % (epoch + 1, time.time() - t0, state.gen_iterations, val_real, val_fake), flush=True)
         if rank == 0:
             netG.save(args.out)                                                                    # GT:892
-            t.save_state(args.state, state)
+            t.save_state(args.state, state, extra=dict(t.rng_to_arrays(rng), order=order, epoch=epoch))
     if rank == 0:
         print("saved", args.out, "and", args.state)
     if dp is not None:

@@ -35,6 +35,10 @@ CONV_CASES = [  # B,H,W,Cin,Cout,k,path
     # path 6: the 8-channel-chunk form of the 3x3 MF = 32 kernel (what launches of >= 1536 items take)
     (2, 32, 32, 32, 32, 3, 6), (2, 48, 40, 32, 64, 3, 6), (1, 32, 32, 224, 96, 3, 6), (2, 21, 19, 64, 160, 3, 6),
     (1, 16, 16, 256, 256, 3, 6), (2, 30, 18, 8, 32, 3, 6),
+    # path 7: the wave-private form (no workgroup barrier in steady state; Cin <= 64): ragged sizes, one and several
+    # channel tiles, one to eight K chunks, persistent (>= 8 super-tiles per XCD form) and one-item workgroups
+    (2, 32, 32, 32, 32, 3, 7), (2, 48, 40, 32, 64, 3, 7), (2, 21, 19, 64, 160, 3, 7), (2, 30, 18, 8, 32, 3, 7),
+    (8, 64, 128, 64, 64, 3, 7), (3, 16, 64, 16, 96, 3, 7),
     (2, 32, 32, 1, 32, 3, 2), (2, 32, 32, 2, 32, 3, 2), (2, 30, 18, 1, 16, 5, 2), (2, 32, 32, 16, 1, 5, 2),
     # single output channel (dD/dx): the 4-pixels-per-thread kernel, ragged tiles, channel tails, both kernel sizes
     (2, 45, 70, 16, 1, 5, 2), (2, 33, 31, 8, 1, 3, 2), (1, 40, 40, 6, 1, 5, 2), (1, 20, 36, 12, 1, 3, 2),
@@ -61,13 +65,45 @@ def test_conv_forward_and_backward_data(lib, case):
     dx = torch.full((B, H, W, ci), float("nan"), device=dev)
     # path 6 (8-channel chunks) exists for 32-channel output tiles only: the backward of a layer with fewer input
     # channels than that runs the 16-channel-chunk kernel
-    bpath = 1 if (path == 6 and ci % 32) else path
+    bpath = 1 if (path in (6, 7) and ci % 32) else path
+    if bpath == 7 and co > 64:
+        bpath = 6            # the backward of this layer has more than 64 input channels: workgroup tiles
     _lib.check(lib.depgan_op_conv2d_bwd_data(P(dyd), P(wd), P(dx), B, H, W, ci, co, k, bpath, None))
     torch.cuda.synchronize()
     xt = torch.from_numpy(x).permute(0, 3, 1, 2).double().requires_grad_(True)
     y = F.conv2d(xt, torch.from_numpy(w).permute(3, 2, 0, 1).double(), padding=k // 2)
     (gx,) = torch.autograd.grad(y, xt, torch.from_numpy(dy).permute(0, 3, 1, 2).double())
     assert rel(dx.cpu().numpy(), gx.permute(0, 2, 3, 1).numpy()) < TOL
+
+
+@pytest.mark.parametrize("case", [(8, 128, 128, 32, 32), (8, 128, 128, 64, 64), (32, 64, 64, 32, 64), (4, 100, 72, 40, 32)])
+def test_wave_private_conv_is_bit_identical_to_the_tile_kernel(lib, case):
+    """csrc/igemm_wp.hip walks K in the order of igemm_conv_kernel<32,3,8,9> (chunk -> tap -> four MFMAs) on the same
+    packed panel and shares its epilogue text: forward and backward-data results must be the same bits, on launches
+    large enough for its persistent form (every workgroup several items, one weight panel each)."""
+    from dep_gan_im_amd import _lib
+    B, H, W, ci, co = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(ci + co + H)
+    x = torch.randn((B, H, W, ci), generator=g).to(dev)
+    w = (torch.randn((3, 3, ci, co), generator=g) / (3.0 * ci ** 0.5)).to(dev)
+    b = torch.randn((co,), generator=g).to(dev)
+    outs = []
+    for path in (6, 7):
+        out = torch.full((B, H, W, co), float("nan"), device=dev)
+        _lib.check(lib.depgan_op_conv2d(P(x), P(w), P(b), P(out), B, H, W, ci, co, 3, 1, path, None))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    if ci % 32 == 0 and co <= 64:
+        dy = torch.randn((B, H, W, co), generator=g).to(dev)
+        dxs = []
+        for path in (6, 7):
+            dx = torch.full((B, H, W, ci), float("nan"), device=dev)
+            _lib.check(lib.depgan_op_conv2d_bwd_data(P(dy), P(w), P(dx), B, H, W, ci, co, 3, path, None))
+            dxs.append(dx)
+        torch.cuda.synchronize()
+        assert torch.equal(dxs[0], dxs[1])
 
 
 def _bf16(a):
