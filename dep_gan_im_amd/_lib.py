@@ -21,7 +21,7 @@ EXPORTS = [
     "depgan_data_prep_scratch_floats", "depgan_data_prep_subject", "depgan_abi_version", "depgan_config_size",
     "depgan_set_allreduce", "depgan_get_adam_step", "depgan_set_adam_step", "depgan_gen_iteration", "depgan_eval_divide",
     "depgan_source_hash", "depgan_debug_capture", "depgan_debug_tensor", "depgan_rccl_unique_id", "depgan_rccl_init",
-    "depgan_rccl_broadcast", "depgan_rccl_info", "depgan_rccl_shutdown",
+    "depgan_rccl_broadcast", "depgan_rccl_info", "depgan_rccl_shutdown", "depgan_op_conv2d_wgrad_bf16",
 ]
 
 ABI_VERSION = 3          # DEPGAN_ABI_VERSION of the include/depgan.h this binding was written against
@@ -121,6 +121,7 @@ def load():
     lib.depgan_op_conv2d.argtypes = [vp, vp, vp, vp] + [C.c_int] * 8 + [vp]
     lib.depgan_op_conv2d_bwd_data.argtypes = [vp, vp, vp] + [C.c_int] * 7 + [vp]
     lib.depgan_op_conv2d_wgrad.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp]
+    lib.depgan_op_conv2d_wgrad_bf16.argtypes = [vp, vp, vp] + [C.c_int] * 6 + [vp]
     lib.depgan_eval_accumulate.argtypes = [vp, vp, vp, C.c_long, vp]
     lib.depgan_eval_divide.argtypes = [vp, C.c_long, C.c_double, vp]
     lib.depgan_eval_counts.argtypes = [vp, C.c_int] + [vp] * 7 + [C.c_long, C.c_double, C.POINTER(C.c_longlong), vp]

@@ -261,6 +261,26 @@ int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, in
   char lb[56];
   snprintf(lb, sizeof(lb), "wgrad k%d b%d %dx%d %d->%d", KS, N, H, W, Cin, Cout);
   const bool mfma = Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 8;
+  // BASELINE configs[3] on the bf16 matrix pipe: the contraction on v_mfma_f32_32x32x16_bf16 (operands rounded while
+  // staged, fp32 accumulation); the column sums keep their own streaming pass
+  if (c->cfg.bf16_mfma && mfma && dg_wgrad_bf16_supported(KS, Cin, Cout)) {
+    if (dg_wgrad_bf16_part_floats(KS, N, H, W, Cin, Cout) > c->partFloats) {
+      dg_set_error("wgrad slab workspace too small");
+      return DG_ERR_ARG;
+    }
+    if (cs) {
+      ProfScope ps(c, 2, 0.0, "colsum");
+      DGCHECK(dg_colsum(dy, cs->B, H, W, Cout, cs->scale, cs->out, cs->raw, 0, c->scratch, c->st));
+    }
+    snprintf(lb, sizeof(lb), "wgrad(bf16) k%d b%d %dx%d %d->%d", KS, N, H, W, Cin, Cout);
+    {
+      ProfScope ps(c, 1, fl, lb);
+      DGCHECK(dg_wgrad_bf16(KS, a, &nch, c->st));
+    }
+    ProfScope ps(c, 2, 0.0, "slab reduce");
+    return dg_wgrad_finish(c->part, nch, KS * KS, Cin, Cout, scale, out, raw, accumulate, oi, nullptr, Cout, nullptr,
+                           nullptr, nullptr, c->st);
+  }
   // Column sums of dy (bias / BN-beta gradients) ride in the MFMA weight-gradient kernel, whose B fragments are the
   // dy values anyway (2 FMAs per 18 MFMAs in one workgroup column; with the register-staged kernel of earlier in the
   // round the same idea cost 10 % -- it sat at the VGPR limit of two workgroups per CU).  The edge-layer kernels keep
@@ -1295,9 +1315,14 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
     for (size_t i = 0; i < c->gl.size(); ++i) {
       const GLayer& L = c->gl[i];
       size_t f = 0;
-      if (L.kind == G_CONV || L.kind == G_FILM)
+      if (L.kind == G_CONV || L.kind == G_FILM) {
         f = (L.Cin >= 8) ? dg_wgrad_part_floats(3, B, L.H, L.W, L.Cin, L.Cout)
                          : dg_wgrad_small_part_floats(3, B, L.H, L.W, L.Cin, L.Cout);
+        if (cfg->bf16_mfma && L.Cin >= 8 && dg_wgrad_bf16_supported(3, L.Cin, L.Cout)) {
+          const size_t fb = dg_wgrad_bf16_part_floats(3, B, L.H, L.W, L.Cin, L.Cout);
+          if (fb > f) f = fb;
+        }
+      }
       else if (L.kind == G_DECONV || (L.kind == G_HEAD && c->train_bn))
         f = dg_wgrad_part_floats(1, B, L.H, L.W, L.Cin, L.Cout);
       if (L.kind == G_DECONV && dg_deconv_wgrad_supported(B, L.H, L.W, L.Cin, L.Cout, L.in, L.dout)) {
@@ -1308,8 +1333,12 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
     }
     for (size_t l = 0; l < c->dl.size(); ++l) {
       const DLayer& L = c->dl[l];
-      const size_t f = (L.Cin >= 8) ? dg_wgrad_part_floats(L.KS, 3 * B, L.H, L.W, L.Cin, L.Cout)
-                                    : dg_wgrad_small_part_floats(L.KS, 3 * B, L.H, L.W, L.Cin, L.Cout);
+      size_t f = (L.Cin >= 8) ? dg_wgrad_part_floats(L.KS, 3 * B, L.H, L.W, L.Cin, L.Cout)
+                              : dg_wgrad_small_part_floats(L.KS, 3 * B, L.H, L.W, L.Cin, L.Cout);
+      if (cfg->bf16_mfma && L.Cin >= 8 && dg_wgrad_bf16_supported(L.KS, L.Cin, L.Cout)) {
+        const size_t fb = dg_wgrad_bf16_part_floats(L.KS, 3 * B, L.H, L.W, L.Cin, L.Cout);
+        if (fb > f) f = fb;
+      }
       if (f > mx) mx = f;
     }
     c->partFloats = mx;
@@ -1844,6 +1873,28 @@ int depgan_op_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, in
   a.colB = 0;
   int nch = 0;
   int rc = big ? dg_wgrad(KS, a, &nch, st) : dg_wgrad_small(KS, a, &nch, st);
+  if (rc == DG_OK) rc = dg_wgrad_reduce(part, nch, KS * KS, Cin, Cout, nullptr, dw, nullptr, 0, 0, st);
+  hipStreamSynchronize(st);
+  hipFree(part);
+  return rc;
+}
+int depgan_op_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                                int KS, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!dg_wgrad_bf16_supported(KS, Cin, Cout)) { dg_set_error("op_wgrad_bf16: shape not covered"); return DG_ERR_UNSUPPORTED; }
+  const size_t pf = dg_wgrad_bf16_part_floats(KS, B, H, W, Cin, Cout);
+  float* part = nullptr;
+  HIPCHECK(hipMalloc((void**)&part, pf * sizeof(float)));
+  WgradArgs a;
+  a.x = make_view(const_cast<float*>(x), H, W, Cin);
+  a.dy = make_view(const_cast<float*>(dy), H, W, Cout);
+  a.part = part;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.nTiles = a.tilesPerChunk = 0;
+  a.colpart = nullptr;
+  a.colB = 0;
+  int nch = 0;
+  int rc = dg_wgrad_bf16(KS, a, &nch, st);
   if (rc == DG_OK) rc = dg_wgrad_reduce(part, nch, KS * KS, Cin, Cout, nullptr, dw, nullptr, 0, 0, st);
   hipStreamSynchronize(st);
   hipFree(part);

@@ -45,9 +45,10 @@ typedef struct depgan_config {
                        0 is read as 1.                                                    */
   int bf16_weights; /* BASELINE config 4: 1 = every "/kernel" tensor is rounded to bf16 (RNE) before use, products
                        accumulate in fp32, the fp32 master copy and the Adam state stay fp32; 0 = fp32 weights */
-  int bf16_mfma;    /* BASELINE config 4 on the bf16 matrix pipe (needs bf16_weights = 1): the MFMA convolutions round
-                       their activation operand to bf16 (RNE) while staging it and run v_mfma_f32_32x32x16_bf16 with
-                       fp32 accumulation; everything between the convolutions stays fp32.  0 = fp32 matrix pipe  */
+  int bf16_mfma;    /* BASELINE config 4 on the bf16 matrix pipe (needs bf16_weights = 1): the MFMA convolutions AND the
+                       weight-gradient contractions round their operands to bf16 (RNE) while staging them and run
+                       v_mfma_f32_32x32x16_bf16 with fp32 accumulation; everything between them stays fp32.
+                       0 = fp32 matrix pipe  */
   int f32_split;    /* 0 (default): fp32 products on v_mfma_f32_32x32x2_f32.  6 or 3 (opt-in, never the benchmark's
                        headline; excludes bf16_weights / bf16_mfma): every fp32 operand of the MFMA convolutions is split
                        exactly into three (two) bf16 terms and the six (three) largest cross products run on
@@ -253,6 +254,10 @@ int depgan_op_conv2d_bwd_data(const float* dy, const float* w_hwio, float* dx, i
                               int Cout, int KS, int path, void* hip_stream);
 int depgan_op_conv2d_wgrad(const float* x, const float* dy, float* dw_hwio, int B, int H, int W, int Cin, int Cout,
                            int KS, void* hip_stream);
+/* the same contraction on the bf16 matrix pipe (depgan_config.bf16_mfma: both operands rounded to bf16, RNE, while
+ * staged; fp32 accumulation).  KS in {1, 3, 5}, Cin >= 8, Cin and Cout multiples of 4; status 3 otherwise. */
+int depgan_op_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw_hwio, int B, int H, int W, int Cin,
+                                int Cout, int KS, void* hip_stream);
 
 /* diagnostics: MFMA conv with per-workgroup phase stamps (16 x u64 per workgroup: start, after first prefetch
  * issue, stage-0 ready, stage-1 ready, MFMAs done, end, realtime ticks, HW_ID) */

@@ -598,16 +598,27 @@ def _bn_train(x, T, name, ch_axis, stats):
     return y
 
 
-def uresnet_forward_t(T, x, z, phase=1, keep_mask=None, stats=None, fm=32, nc_out=4):
+def _pool_gather(a, idx):
+    B, C = a.shape[:2]
+    return a.reshape(B, C, -1).gather(2, idx.reshape(B, C, -1)).reshape(idx.shape)
+
+
+def uresnet_forward_t(T, x, z, phase=1, keep_mask=None, stats=None, fm=32, nc_out=4, masks=None):
     """DEP-UResNet forward.  x (B,H,W,1), z (B,32,1); keep_mask: NHWC {0,1} mask for do_gen_1 (phase 1).
-    Returns softmax probabilities (B,H,W,nc_out)."""
+    Returns softmax probabilities (B,H,W,nc_out).
+    masks: None, or the ReLU signs / pool arg-maxes as data (oracle.manual.generator_masks: what the HIP path decided) --
+    relu(v) becomes v * mask and max-pooling a gather, which makes the step smooth in the weights (tests/test_gpu_masked.py
+    explains why the gradient tests pin them)."""
     def bn(v, name, ch_axis=1):
         return _bn_train(v, T, name, ch_axis, stats) if phase == 1 else _bn_infer(v, T, name, ch_axis)
 
+    def relu(v, key):
+        return torch.relu(v) if masks is None else v * masks[key]
+
     h = z @ T["dense_noise_1_add_f0/kernel"] + T["dense_noise_1_add_f0/bias"]
-    h = torch.relu(bn(h, "dense_bn_noise_1_add_f0", 2))
+    h = relu(bn(h, "dense_bn_noise_1_add_f0", 2), "noise_a0")
     h = h @ T["dense_noise_1_add_f1/kernel"] + T["dense_noise_1_add_f1/bias"]
-    h = torch.relu(bn(h, "dense_bn_noise_1_add_f1", 2))
+    h = relu(bn(h, "dense_bn_noise_1_add_f1", 2), "noise_a1")
     flat = h.reshape(h.shape[0], -1)
     heads = {}
     for sfx, _ in NOISE_HEADS:
@@ -618,20 +629,20 @@ def uresnet_forward_t(T, x, z, phase=1, keep_mask=None, stats=None, fm=32, nc_ou
     for ent in gen_trunk(1, fm, nc_out):
         kind, name = ent[0], ent[1]
         if kind == "conv":
-            a = torch.relu(bn(_conv_same(a, T["conv2d_" + name + "/kernel"], T["conv2d_" + name + "/bias"]), "bn_" + name))
+            a = relu(bn(_conv_same(a, T["conv2d_" + name + "/kernel"], T["conv2d_" + name + "/bias"]), "bn_" + name), name)
             if name == "gen_10" and phase == 1 and keep_mask is not None:      # do_gen_1, UT:388
                 a = a * _nchw(keep_mask.to(a.dtype)) / (1.0 - DROP_RATE)
         elif kind == "film":
             mul_n, add_n = film_names(ent[4])
             u = bn(_conv_same(a, T["conv2d_" + name + "/kernel"], T["conv2d_" + name + "/bias"]), "bn_" + name)
-            a = torch.relu(u * heads[mul_n][:, :, None, None] + heads[add_n][:, :, None, None]) + a
+            a = relu(u * heads[mul_n][:, :, None, None] + heads[add_n][:, :, None, None], name) + a
         elif kind == "pool":
             skips[name] = a
-            a = F.max_pool2d(a, 2)
+            a = F.max_pool2d(a, 2) if masks is None else _pool_gather(a, masks[name])
         elif kind == "deconv":
             w = T["deconv2d_" + name + "/kernel"]
             a = F.conv_transpose2d(a, w.permute(3, 2, 0, 1), T["deconv2d_" + name + "/bias"], stride=2)
-            a = torch.relu(bn(a, "bn_" + name))
+            a = relu(bn(a, "bn_" + name), name)
             a = torch.cat([a, skips[ent[4]]], dim=1)
         elif kind == "head":
             a = torch.softmax(_conv_same(a, T[name + "/kernel"], T[name + "/bias"]), dim=1)
@@ -650,9 +661,9 @@ def uresnet_predict(P, x, z, dtype=torch.float32):
         return uresnet_forward_t(to_torch(P, dtype), _t(x, dtype), _t(z, dtype), phase=0).numpy()
 
 
-def uresnet_grads(P, x, z, labels, drop_seed=None, dtype=torch.float32):
+def uresnet_grads(P, x, z, labels, drop_seed=None, dtype=torch.float32, masks=None):
     """One Model.train_on_batch worth of gradients (phase 1).  labels: one-hot (B,H,W,4).
-    Returns (loss, grads dict, batch BN stats dict)."""
+    Returns (loss, grads dict, batch BN stats dict).  masks: see uresnet_forward_t."""
     T = to_torch(P, dtype, requires_grad=True)
     xt, zt, lt = _t(x, dtype), _t(z, dtype), _t(np.asarray(labels, np.float32), dtype)
     keep = None
@@ -660,7 +671,7 @@ def uresnet_grads(P, x, z, labels, drop_seed=None, dtype=torch.float32):
         B, H, W, _ = xt.shape
         keep = torch.tensor(dropout_keep_mask(drop_seed, (B, H // 4, W // 4, 96)))
     stats = {}
-    p = uresnet_forward_t(T, xt, zt, phase=1, keep_mask=keep, stats=stats)
+    p = uresnet_forward_t(T, xt, zt, phase=1, keep_mask=keep, stats=stats, masks=masks)
     loss = keras_categorical_crossentropy_t(p, lt)
     names = trainable_names(P)
     gs = torch.autograd.grad(loss, [T[n] for n in names], allow_unused=True)
@@ -675,9 +686,9 @@ class OracleUResNet:
         self.P, self.dtype = P, dtype
         self.opt = KerasAdam(trainable_names(P), lr, 0.9, 0.999)
 
-    def train_on_batch(self, inputs, labels, drop_seed=None):
+    def train_on_batch(self, inputs, labels, drop_seed=None, masks=None):
         x, z = inputs
-        loss, grads, stats = uresnet_grads(self.P, x, z, labels, drop_seed, self.dtype)
+        loss, grads, stats = uresnet_grads(self.P, x, z, labels, drop_seed, self.dtype, masks)
         self.opt.apply(self.P, grads)
         for name, (mean, var, n, fused) in stats.items():
             # moving variance: Bessel-corrected on the fused 4-D path, n/(n-(1+eps)) on the generic path

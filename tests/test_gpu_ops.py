@@ -223,6 +223,42 @@ def test_conv_weight_gradient(lib, case):
     assert torch.equal(dw, dw2)
 
 
+WGRAD_BF16_CASES = [(2, 32, 32, 32, 32, 3), (3, 48, 40, 64, 64, 3), (2, 23, 17, 96, 32, 3), (2, 16, 16, 256, 256, 3),
+                    (2, 32, 32, 16, 16, 5), (2, 32, 32, 16, 32, 5), (2, 32, 24, 32, 32, 5), (2, 32, 32, 128, 128, 1),
+                    (4, 64, 64, 32, 64, 3), (2, 32, 32, 48, 80, 3), (8, 128, 128, 32, 32, 3), (2, 30, 18, 8, 12, 3)]
+
+
+@pytest.mark.parametrize("case", WGRAD_BF16_CASES)
+def test_bf16_mfma_conv_weight_gradient(lib, case):
+    """csrc/wgrad_bf16.hip (BASELINE configs[3]: the weight-gradient contraction on v_mfma_f32_32x32x16_bf16, operands
+    rounded to bf16 while staged, fp32 accumulation; K-major fragments through ds_read_b64_tr_b16) against the float64
+    contraction of the SAME rounded operands: 1e-4, every tap, channel tails, ragged tiles; bit-reproducible."""
+    from dep_gan_im_amd import _lib
+    B, H, W, ci, co, k = case
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(ci * 79 + co + k)
+    x = rng.standard_normal((B, H, W, ci)).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, co)).astype(np.float32)
+    xd, dyd = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+    dw = torch.full((k, k, ci, co), float("nan"), device=dev)
+    _lib.check(lib.depgan_op_conv2d_wgrad_bf16(P(xd), P(dyd), P(dw), B, H, W, ci, co, k, None))
+    torch.cuda.synchronize()
+    wt = torch.zeros((co, ci, k, k), dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(torch.from_numpy(_bf16(x)).permute(0, 3, 1, 2).double(), wt, padding=k // 2)
+    (gw,) = torch.autograd.grad(y, wt, torch.from_numpy(_bf16(dy)).permute(0, 3, 1, 2).double())
+    want = gw.permute(2, 3, 1, 0).numpy()
+    assert rel(dw.cpu().numpy(), want) < TOL
+    # the rounding is visible (this is not the fp32 contraction) ...
+    y32 = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2).double(), wt, padding=k // 2)
+    (gw32,) = torch.autograd.grad(y32, wt, torch.from_numpy(dy).permute(0, 3, 1, 2).double())
+    assert rel(want, gw32.permute(2, 3, 1, 0).numpy()) > 10 * rel(dw.cpu().numpy(), want)
+    # ... and the launch is bit-reproducible (deterministic slab reduction)
+    dw2 = torch.empty_like(dw)
+    _lib.check(lib.depgan_op_conv2d_wgrad_bf16(P(xd), P(dyd), P(dw2), B, H, W, ci, co, k, None))
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2)
+
+
 DECONV_CASES = [  # B,H,W,Cin,Cout,affine: the three instantiations (64 / 96 / 128 input channels), two channel
     # halves per pixel tile (Cout = 128), image rows shorter than a 32-pixel tile, H != W
     (2, 32, 32, 64, 64, True), (1, 16, 64, 96, 96, True), (2, 16, 16, 128, 128, True), (4, 8, 8, 64, 64, False),

@@ -88,6 +88,38 @@ def test_predict_eval_and_grads_match_golden_and_oracle(lib):
     eng.close()
 
 
+@pytest.mark.parametrize("ds", [0, 77], ids=["no_dropout", "dropout"])
+def test_phase1_gradients_under_hip_masks(lib, ds):
+    """The learning-phase-1 gradient (UT:423-427, 602-606: batch-statistics BatchNorm differentiated through, Dropout,
+    softmax + cross-entropy) against the fp64 oracle evaluated under the ReLU signs / pool arg-maxes / FiLM signs the
+    HIP pass took (tests/test_gpu_masked.py): per tensor, every evaluation.  Biases in front of a batch-statistics BN
+    have an exactly zero gradient; they must be zero to the rounding of the largest gradient entry."""
+    import test_gpu_masked as TM
+    from oracle import depgan_oracle as O
+    img, B = 64, 4
+    P = _mg().uresnet_params(5)
+    x, z, lab = O.synth_uresnet_batch(6, B, img, img)
+    eng = _engine(img, B, P)
+    loss = eng.uresnet(x, z, lab, "grads", drop_seed=ds)
+    G = eng.get_grads("G")
+    masks = TM.hip_uresnet_masks(eng, B)
+    loss64, g64, _ = O.uresnet_grads(P, x, z, lab, drop_seed=ds or None, dtype=torch.float64, masks=masks)
+    _, g32, _ = O.uresnet_grads(P, x, z, lab, drop_seed=ds or None, dtype=torch.float32, masks=masks)
+    assert abs(loss - loss64) < 1e-5 * max(1.0, abs(loss64))
+    errs, errs32 = TM.tensor_errors(G, g64), TM.tensor_errors(g32, g64)
+    worst = max(errs, key=errs.get)
+    print("DEP-UResNet phase-1 gradient under HIP's masks (%s): worst tensor %s %.2e (the oracle's own fp32 run under the "
+          "same masks: %.2e on it, %.2e at its worst)" % ("dropout" if ds else "no dropout", worst, errs[worst],
+                                                          errs32[worst], max(errs32.values())))
+    # With the decisions pinned what is left is conditioning: every batch-statistics BN subtracts the mean of the incoming
+    # gradient (the 14 noise-head BNs over a batch of FOUR rows), so some tensors are small residuals of large terms in
+    # any fp32 arithmetic.  Per tensor: 1e-4, or three times what the CPU's fp32 evaluation of the same masked graph loses.
+    for k in errs:
+        assert errs[k] < max(1e-4, 3.0 * errs32[k]), (k, errs[k], errs32[k])
+    assert sum(e > 1e-4 for e in errs.values()) <= 8, sorted(errs.items(), key=lambda kv: -kv[1])[:10]
+    eng.close()
+
+
 def test_dropout_mask_is_the_oracles(lib):
     """drop_seed selects the same keep mask as oracle.dropout_keep_mask: with dropout on, the loss moves exactly
     as the oracle's does, and seed 0 means no dropout."""
