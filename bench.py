@@ -206,11 +206,11 @@ def bench_config4(dg, torch, dev, B, steps=5):
     gbs = c_by / (c_ms * 1e-3) / 1e9 if c_ms > 0 else 0.0
     return {"workload": "BASELINE configs[3]: canonical train step, DEP-GAN-PROB 2-channel input 256x256x2, batch %d, "
                         "bf16 weights and bf16 activations into v_mfma_f32_32x32x16_bf16, fp32 accumulate / masters / "
-                        "Adam; weight-gradient contractions (activation x gradient, no weights in them) stay on the "
-                        "fp32 pipe" % B,
+                        "Adam; the weight-gradient contractions run on the same pipe (operands rounded to bf16 while "
+                        "staged, K-major fragments through ds_read_b64_tr_b16)" % B,
             "dtype": "bf16 operands, f32 accumulate", "ms_per_step": round(ms, 3),
             "slices_per_s": round(B / (ms * 1e-3), 1),
-            "ms_per_step_by_class": {"conv": round(c_ms, 3), "wgrad_fp32": round(w_ms, 3), "other": round(o_ms, 3)},
+            "ms_per_step_by_class": {"conv": round(c_ms, 3), "wgrad": round(w_ms, 3), "other": round(o_ms, 3)},
             "g_forward_ms": round(gf, 3),
             "roofline": {"kernel": "igemm_bf16_kernel + the 16-channel layers left on the fp32 pipe (conv class)",
                          "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",

@@ -257,7 +257,7 @@ int dg_wgrad_reduce(const float* part, int nchunks, int ntaps, int Cin, int Cout
                     float* raw, int accumulate, int oi, hipStream_t st);
 
 // bf16 matrix pipe (wgrad_bf16.hip, BASELINE configs[3]): operands rounded to bf16 while staged, fp32 accumulation;
-// same slab format and finish launch as dg_wgrad (no column sums: the caller runs dg_colsum)
+// same slab format, column-sum rows ([nchunks][Cout], samples b < colB) and finish launch as dg_wgrad
 bool dg_wgrad_bf16_supported(int KS, int Cin, int Cout);
 size_t dg_wgrad_bf16_part_floats(int KS, int B, int H, int W, int Cin, int Cout);
 int dg_wgrad_bf16(int KS, const WgradArgs& a, int* nchunks, hipStream_t st);

@@ -269,8 +269,8 @@ int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, in
       return DG_ERR_ARG;
     }
     if (cs) {
-      ProfScope ps(c, 2, 0.0, "colsum");
-      DGCHECK(dg_colsum(dy, cs->B, H, W, Cout, cs->scale, cs->out, cs->raw, 0, c->scratch, c->st));
+      a.colpart = c->scratch;
+      a.colB = cs->B;
     }
     snprintf(lb, sizeof(lb), "wgrad(bf16) k%d b%d %dx%d %d->%d", KS, N, H, W, Cin, Cout);
     {
@@ -278,8 +278,8 @@ int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, in
       DGCHECK(dg_wgrad_bf16(KS, a, &nch, c->st));
     }
     ProfScope ps(c, 2, 0.0, "slab reduce");
-    return dg_wgrad_finish(c->part, nch, KS * KS, Cin, Cout, scale, out, raw, accumulate, oi, nullptr, Cout, nullptr,
-                           nullptr, nullptr, c->st);
+    return dg_wgrad_finish(c->part, nch, KS * KS, Cin, Cout, scale, out, raw, accumulate, oi, cs ? c->scratch : nullptr,
+                           Cout, cs ? cs->scale : nullptr, cs ? cs->out : nullptr, cs ? cs->raw : nullptr, c->st);
   }
   // Column sums of dy (bias / BN-beta gradients) ride in the MFMA weight-gradient kernel, whose B fragments are the
   // dy values anyway (2 FMAs per 18 MFMAs in one workgroup column; with the register-staged kernel of earlier in the

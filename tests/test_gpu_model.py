@@ -415,6 +415,18 @@ def test_config4_bf16_matrix_pipe(lib):
     d_w = O.d_predict(O.round_kernels_bf16(PD1), y2)
     d_got = eng.d_forward("D_y2", y2).cpu().numpy()
     assert rel(d_got, d_q) < 2.0 * rel(d_q, d_w) + 1e-3, (rel(d_got, d_q), rel(d_q, d_w))
+    # one critic gradient: kernels (wgrad_bf16.hip: both operands rounded) and biases (its in-kernel column sums of the
+    # unrounded upstream gradient) against the rounded-operand oracle, at the level the activation rounding allows
+    eng.critic("D_y2", y2, x, z, ep, update=False)
+    gg = eng.get_grads("D_y2")
+    with O.bf16_activations():
+        _, gq, _ = O.critic_grads(O.round_kernels_bf16(PD1), O.round_kernels_bf16(PG), y2, x, z, ep, "y2", nicg=2,
+                                  dtype=torch.float64)
+    for sfx in ("/kernel", "/bias"):
+        ks = [k for k in gq if k.endswith(sfx) and float(np.abs(gq[k]).max()) > 0]
+        l2 = np.sqrt(sum(((gg[k] - gq[k]) ** 2).sum() for k in ks) / sum((gq[k] ** 2).sum() for k in ks))
+        print("config 4 bf16 pipe: critic-Y2 %s gradients rel-L2 vs the rounded-operand oracle %.2e" % (sfx, l2))
+        assert l2 < 5e-2, (sfx, l2)
     ref = O.OracleTrainers(PG, PD1, PD2, nicg=2, dtype=torch.float64, weights_dtype="bfloat16",
                            activations_dtype="bfloat16")
     moved = False
