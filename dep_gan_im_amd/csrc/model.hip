@@ -7,6 +7,7 @@
 
 #include <dlfcn.h>
 #include <math.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -263,7 +264,7 @@ int wgrad_full(depgan_ctx* c, int KS, TView x, TView dy, int N, int H, int W, in
   const bool mfma = Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 8;
   // BASELINE configs[3] on the bf16 matrix pipe: the contraction on v_mfma_f32_32x32x16_bf16 (operands rounded while
   // staged, fp32 accumulation); the column sums keep their own streaming pass
-  if (c->cfg.bf16_mfma && mfma && dg_wgrad_bf16_supported(KS, Cin, Cout)) {
+  if (c->cfg.bf16_mfma && mfma && c->wgrad_bf16 && dg_wgrad_bf16_supported(KS, Cin, Cout)) {
     if (dg_wgrad_bf16_part_floats(KS, N, H, W, Cin, Cout) > c->partFloats) {
       dg_set_error("wgrad slab workspace too small");
       return DG_ERR_ARG;
@@ -1297,6 +1298,12 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
   depgan_ctx* c = new depgan_ctx();
   c->cfg = *cfg;
   if (hipGetDevice(&c->device) != hipSuccess) c->device = 0;
+  {
+    // DEPGAN_WGRAD_BF16=0 (read when the context is created): a bf16_mfma context keeps the fp32 weight-gradient kernel
+    // -- the A/B switch of tests/test_gpu_model.py::test_config4_bf16_matrix_pipe
+    const char* e = getenv("DEPGAN_WGRAD_BF16");
+    c->wgrad_bf16 = !(e && atoi(e) == 0);
+  }
   if (c->cfg.nc_out <= 0) c->cfg.nc_out = 1;
   if (c->cfg.nc_out != 1 && c->cfg.nc_out != 4) {
     dg_set_error("depgan_create: nc_out must be 1 (DEP-GAN) or 4 (DEP-UResNet)");

@@ -121,10 +121,110 @@ static int colsum2_launch(int mode, TView v, TView w, const float* m, int B, int
   return DG_OK;
 }
 
+// Batch mean and (biased) variance per channel in ONE pass over the tensor (round 3; was two: mean, then centred squares).
+// Plain E[x^2] - E[x]^2 loses the variance of channels with |mean| >> sigma, so every block sums (x - s) and (x - s)^2
+// around a shift s of its own -- the value of its first pixel, a sample of the very distribution, so |mean_b - s| is a
+// few sigma and the block's subtraction M2_b = S2 - S1^2 / n_b is benign -- and the per-channel finish combines the
+// blocks' (n_b, mean_b, M2_b) with the parallel-variance formula (Chan et al.) in double precision:
+//   mean = sum n_b mean_b / N,   M2 = sum M2_b + sum n_b (mean_b - mean)^2,   var = M2 / N.
+template <bool FLAT>
+__global__ void moments_partial(TView v, long npix, int H, int W, int C4, float* __restrict__ part, int pixPerBlock) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [256][8]
+  const int LP = C4, PP = 256 / LP;
+  const int lp = threadIdx.x % LP, pp = threadIdx.x / LP;
+  const long q0 = (long)blockIdx.x * pixPerBlock, q1 = min(q0 + pixPerBlock, npix);
+  auto off = [&](long q) -> long {
+    if (FLAT) return q * v.sX;
+    const int x = (int)(q % W);
+    const long r = q / W;
+    return view_off(v, (int)(r / H), (int)(r % H), x);
+  };
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+  if (pp < PP) {
+    sv = *reinterpret_cast<const f32x4*>(v.p + off(q0) + lp * 4);          // the block's shift: its first pixel
+    for (long q = q0 + pp; q < q1; q += PP) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(v.p + off(q) + lp * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = xv[k] - sv[k];
+        a0[k] += d;
+        a1[k] = fmaf(d, d, a1[k]);
+      }
+    }
+  }
+  *reinterpret_cast<f32x4*>(sh + threadIdx.x * 8) = a0;
+  *reinterpret_cast<f32x4*>(sh + threadIdx.x * 8 + 4) = a1;
+  __syncthreads();
+  const int C = C4 * 4;
+  for (int idx = threadIdx.x; idx < LP * 8; idx += 256) {
+    const int l = idx / 8, k = idx % 8;
+    float s = 0.f;
+    for (int j = 0; j < PP; ++j) s += sh[(j * LP + l) * 8 + k];
+    part[((size_t)blockIdx.x * 3 + (k >> 2)) * C + l * 4 + (k & 3)] = s;
+  }
+  if (pp == 0) *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 3 + 2) * C + lp * 4) = sv;
+}
+// one block per channel: Chan's combination of the blocks' (n_b, mean_b, M2_b), double precision, fixed order
+__global__ void moments_final(const float* __restrict__ part, int nb, int C, long npix, int pixPerBlock,
+                              float* __restrict__ mean, float* __restrict__ var) {
+  __shared__ double shd[256];
+  const int c = blockIdx.x;
+  auto nof = [&](int b) -> double {
+    const long q0 = (long)b * pixPerBlock;
+    const long q1 = q0 + pixPerBlock < npix ? q0 + pixPerBlock : npix;
+    return (double)(q1 - q0);
+  };
+  auto block_sum = [&](double x) -> double {
+    shd[threadIdx.x] = x;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o];
+      __syncthreads();
+    }
+    const double r = shd[0];
+    __syncthreads();
+    return r;
+  };
+  double sm = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 256) {
+    const double s1 = part[((size_t)b * 3 + 0) * C + c], sh_ = part[((size_t)b * 3 + 2) * C + c];
+    sm += nof(b) * sh_ + s1;                       // n_b mean_b = n_b s_b + S1_b
+  }
+  const double mu = block_sum(sm) / (double)npix;
+  double m2 = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 256) {
+    const double n = nof(b);
+    const double s1 = part[((size_t)b * 3 + 0) * C + c], s2 = part[((size_t)b * 3 + 1) * C + c];
+    const double mb = (double)part[((size_t)b * 3 + 2) * C + c] + s1 / n;
+    m2 += (s2 - s1 * s1 / n) + n * (mb - mu) * (mb - mu);
+  }
+  const double M2 = block_sum(m2);
+  if (threadIdx.x == 0) {
+    mean[c] = (float)mu;
+    var[c] = (float)(M2 / (double)npix);
+  }
+}
+
 int dg_col_moments(TView v, int B, int H, int W, int C, float* mean, float* var, float* scratch, hipStream_t st) {
-  const float invN = 1.0f / (float)((long)B * H * W);
-  DGCHECK(colsum2_launch(0, v, null_view(), nullptr, B, H, W, C, invN, mean, nullptr, scratch, st));
-  return colsum2_launch(1, v, null_view(), mean, B, H, W, C, invN, var, nullptr, scratch, st);
+  if ((C % 4) || C > 1024) {
+    dg_set_error("train moments: C must be a multiple of 4 and <= 1024 (got %d)", C);
+    return DG_ERR_ARG;
+  }
+  const long npix = (long)B * H * W;
+  int nb = (int)((npix + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  const int ppb = (int)((npix + nb - 1) / nb);
+  nb = (int)((npix + ppb - 1) / ppb);
+  const size_t lds = 256 * 8 * sizeof(float);
+  const bool flat = (v.sY == (long)W * v.sX && v.sB == (long)H * v.sY);
+  if (flat)
+    hipLaunchKernelGGL((moments_partial<true>), dim3(nb), dim3(256), lds, st, v, npix, H, W, C / 4, scratch, ppb);
+  else
+    hipLaunchKernelGGL((moments_partial<false>), dim3(nb), dim3(256), lds, st, v, npix, H, W, C / 4, scratch, ppb);
+  HIPCHECK(hipGetLastError());
+  hipLaunchKernelGGL(moments_final, dim3(C), dim3(256), 0, st, scratch, nb, C, npix, ppb, mean, var);
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
 }
 int dg_colsum_pair(TView d, TView x, const float* mean, int B, int H, int W, int C, float* sums, float* scratch,
                    hipStream_t st) {

@@ -156,14 +156,14 @@ class _Model:
 
     def load_weights(self, path):
         """`.npz` written by save_weights, or a Keras 2.x HDF5 file (`model.save` / `save_weights`: GT:892, GE:383)
-        when h5py is installed -- the names and layouts here are the Keras ones, so that import is a lookup."""
+        through h5py when it is installed and through dep_gan_im_amd.h5lite otherwise -- the names and layouts here are
+        the Keras ones, so that import is a lookup."""
         if str(path).lower().endswith((".h5", ".hdf5")):
             try:
-                import h5py
-            except ImportError as e:
-                raise ImportError("reading Keras HDF5 weights needs h5py (not installed); convert the file to .npz "
-                                  "with weights_from_keras_h5 on a machine that has it") from e
-            with h5py.File(path, "r") as f:
+                import h5py as h5
+            except ImportError:
+                from . import h5lite as h5      # pure-Python reader of the HDF5 subset Keras weight files use
+            with h5.File(path, "r") as f:
                 self.set_weights(weights_from_keras_h5(f, [n for n, _, _ in self._named_table()]))
             return
         with np.load(path) as f:

@@ -415,18 +415,37 @@ def test_config4_bf16_matrix_pipe(lib):
     d_w = O.d_predict(O.round_kernels_bf16(PD1), y2)
     d_got = eng.d_forward("D_y2", y2).cpu().numpy()
     assert rel(d_got, d_q) < 2.0 * rel(d_q, d_w) + 1e-3, (rel(d_got, d_q), rel(d_q, d_w))
-    # one critic gradient: kernels (wgrad_bf16.hip: both operands rounded) and biases (its in-kernel column sums of the
-    # unrounded upstream gradient) against the rounded-operand oracle, at the level the activation rounding allows
+    # The weight-gradient kernel of this mode (wgrad_bf16.hip: both operands rounded to bf16, column sums of the unrounded
+    # upstream gradient folded in-kernel) inside the engine: the same context with DEPGAN_WGRAD_BF16=0 runs the fp32
+    # weight-gradient kernel on the SAME activations and upstream gradients (forward and backward-data are the same bf16
+    # launches, bit for bit), so the two gradients differ by the contraction's operand rounding only -- kernels by a few
+    # 1e-3 of their norm, biases (plain sums on both sides) by summation order.  (Against the oracle the critic gradient
+    # of this mode is not comparable that tightly: the rounding noise of the activations, 4e-3 per element, flips
+    # thousands of ReLU / arg-max decisions -- measured 0.3 relative L2 at this random initialisation.)
     eng.critic("D_y2", y2, x, z, ep, update=False)
     gg = eng.get_grads("D_y2")
-    with O.bf16_activations():
-        _, gq, _ = O.critic_grads(O.round_kernels_bf16(PD1), O.round_kernels_bf16(PG), y2, x, z, ep, "y2", nicg=2,
-                                  dtype=torch.float64)
-    for sfx in ("/kernel", "/bias"):
-        ks = [k for k in gq if k.endswith(sfx) and float(np.abs(gq[k]).max()) > 0]
-        l2 = np.sqrt(sum(((gg[k] - gq[k]) ** 2).sum() for k in ks) / sum((gq[k] ** 2).sum() for k in ks))
-        print("config 4 bf16 pipe: critic-Y2 %s gradients rel-L2 vs the rounded-operand oracle %.2e" % (sfx, l2))
-        assert l2 < 5e-2, (sfx, l2)
+    eng.generator(x, y2, z, "grads")
+    ggG = eng.get_grads("G")
+    os.environ["DEPGAN_WGRAD_BF16"] = "0"
+    try:
+        eng32 = dg.Engine(B, img, img, 2, bf16_mfma=True)
+        for n, P in (("G", PG), ("D_y2", PD1), ("D_dem", PD2)):
+            eng32.set_weights(n, P)
+        eng32.critic("D_y2", y2, x, z, ep, update=False)
+        g32 = eng32.get_grads("D_y2")
+        eng32.generator(x, y2, z, "grads")
+        g32G = eng32.get_grads("G")
+        eng32.close()
+    finally:
+        del os.environ["DEPGAN_WGRAD_BF16"]
+    for net, a_, b_ in (("D_y2", gg, g32), ("G", ggG, g32G)):
+        for sfx, tol in (("/kernel", 2e-2), ("/bias", 1e-4)):
+            ks = [k for k in b_ if k.endswith(sfx) and float(np.abs(b_[k]).max()) > 0]
+            l2 = np.sqrt(sum(((a_[k] - b_[k]) ** 2).sum() for k in ks) / sum((b_[k] ** 2).sum() for k in ks))
+            print("config 4 bf16 pipe: %s %s gradients, bf16 vs fp32 weight-gradient kernel on the same operands: rel-L2 "
+                  "%.2e" % (net, sfx, l2))
+            assert l2 < tol, (net, sfx, l2)
+        assert any(not np.array_equal(a_[k], b_[k]) for k in b_ if k.endswith("/kernel"))    # it IS another kernel
     ref = O.OracleTrainers(PG, PD1, PD2, nicg=2, dtype=torch.float64, weights_dtype="bfloat16",
                            activations_dtype="bfloat16")
     moved = False
