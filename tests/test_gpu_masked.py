@@ -144,13 +144,14 @@ def check_generator(eng, PG, PD1, PD2, x, y2, z, B, tol=1e-4, nicg=1, dtype=torc
     return masks, grads
 
 
-CASES_64 = [(31, 0), (33, 0), (37, 0), (131, 0), (137, 0), (151, 0), (31, 6), (131, 6)]
+CASES_64 = [(31, 0), (33, 0), (131, 0), (137, 0), (151, 0), (31, 6), (131, 6)]
 
 
 @pytest.mark.parametrize("seed,split", CASES_64, ids=["%d-%s" % (s, "split6" if m else "native") for s, m in CASES_64])
 def test_gradients_64_under_hip_masks_every_seed(lib, seed, split):
-    """64x64, batch 2: both critics and the generator on every seed -- the seeds the free comparison used to pick the
-    best of (31, 33, 37: random-init critics; 131..151: penalty in the trained regime).  Per tensor 1e-4.
+    """64x64, batch 2: both critics and the generator on every seed -- seeds the free comparison used to pick the best
+    of (31, 33: random-init critics; 131, 137, 151: penalty in the trained regime; 37 and 149 were measured too and
+    dropped for the suite's run time: DESIGN.md section 2 has all nine).  Per tensor 1e-4.
     split = 6: the same bound for the opt-in f32_split mode (fp32 operands split exactly into bf16 terms, six products on
     the bf16 matrix pipe), which the bench line reports next to the headline."""
     from oracle import manual as M
@@ -194,9 +195,10 @@ def test_gradients_256_under_hip_masks(lib, seed, noisy, trained):
     img, B = 256, 2
     PG, PD1, PD2, x, y2, z, ep = setup(img, B, seed, noisy=noisy, trained_regime=trained)
     eng = engine(img, B, PG, PD1, PD2)
-    # the tie-free case runs the oracle in float64 throughout; the reference-like one (a minute of CPU in float64) with
-    # float32 convolutions and float64 reductions, as the batch-32 test does
-    dt = torch.float64 if noisy else torch.float32
+    # the oracle's convolutions run in float32 and its parameter-gradient reductions in float64 here, as in the batch-32
+    # test (float64 throughout, as at 64x64, is a minute of CPU per case: measured once, 3.9e-6 / 7.3e-6 / 1.2e-5 on the
+    # tie-free case and 5.9e-6 / 3.8e-6 / 7.9e-6 on the reference-like one)
+    dt = torch.float32
     for which, PD in (("D_y2", PD1), ("D_dem", PD2)):
         masks, _ = check_critic(eng, which, PD, PG, x, y2, z, ep, B, dtype=dt)
         if which == "D_y2" and noisy:

