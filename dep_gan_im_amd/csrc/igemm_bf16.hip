@@ -24,12 +24,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-// PERS (round 3): persistent workgroups, two per CU, each walking the items id, id + G, ...  This kernel waits for
-// memory, not for the matrix pipe (18 MFMAs of 32 cycles per 32-channel chunk), so what the persistent form buys is
-// (i) the per-thread staging geometry computed once per workgroup instead of ~1000 vector instructions per item, and
-// (ii) the NEXT item's first chunk requested before the current item's epilogue: its HBM latency passes under the
-// epilogue's transpose and stores instead of in front of the next item's first barrier.
-template <int KS, int TAPG, bool PERS>
+template <int KS, int TAPG>
 __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const ConvArgs a) {
   constexpr int MF = 32, NT = 32, MT = 2, CK = 32;
   constexpr int PAD = KS / 2;
@@ -56,43 +51,30 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const ConvArgs a) {
   // work item -> (pixel tile, channel tile): the XCD-aware order of igemm_conv.hip (each XCD walks a contiguous eighth
   // of the pixel tiles with the channel tile fastest)
   const unsigned nNTall = (unsigned)a.lgy, nPix = (unsigned)a.lgx;
+  const unsigned id = blockIdx.x;
+  int t, ntile;
+  if ((nPix & 7u) == 0) {
+    const unsigned x = id & 7u, sl = id >> 3;
+    ntile = (int)(sl % nNTall);
+    t = (int)(x * (nPix >> 3) + sl / nNTall);
+  } else {
+    t = (int)(id % nPix);
+    ntile = (int)(id / nPix);
+  }
+  const int tx0 = (t % tilesX) * 16;
+  t /= tilesX;
+  const int ty0 = (t % tilesY) * 16;
+  const int b = t / tilesY;
   const int ngrp = a.groups > 1 ? a.groups : 1;
   const int nNTg = (int)nNTall / ngrp;
+  const int grp = ntile / nNTg;
+  ntile -= grp * nNTg;
+  const __bf16* wbase = reinterpret_cast<const __bf16*>(a.groups > 1 ? a.w_group[grp] : a.w);
+  const long out_goff = a.groups > 1 ? a.out_group_off[grp] : 0;
+  const int n0 = ntile * NT;
   const int nCC = (a.Cin + CK - 1) / CK;
   const int NS = nCC * NG;
-  struct Item {
-    int b, ty0, tx0, ntile, grp;
-  };
-  auto decode = [&](unsigned id) {
-    int t, ntile;
-    if ((nPix & 7u) == 0) {
-      const unsigned x = id & 7u, sl = id >> 3;
-      ntile = (int)(sl % nNTall);
-      t = (int)(x * (nPix >> 3) + sl / nNTall);
-    } else {
-      t = (int)(id % nPix);
-      ntile = (int)(id / nPix);
-    }
-    Item it;
-    it.tx0 = (t % tilesX) * 16;
-    t /= tilesX;
-    it.ty0 = (t % tilesY) * 16;
-    it.b = t / tilesY;
-    it.grp = ntile / nNTg;
-    it.ntile = ntile - it.grp * nNTg;
-    return it;
-  };
-
-  // per-thread staging geometry (the persistent form keeps it in registers for the life of the workgroup)
-  int xgo[XPIECES], xyx[XPIECES];
-#pragma unroll
-  for (int i = 0; i < XPIECES; ++i) {
-    const int q = min(tid + i * 256, XTOT - 1);
-    const int pix = q / XV, part = q - pix * XV;
-    const int ly = pix / TW, lx = pix - ly * TW;
-    xgo[i] = ly * (int)a.in.sY + lx * (int)a.in.sX + part * 4;
-    xyx[i] = (ly << 16) | (lx << 8) | (part * 4);
-  }
+  const float* inb = a.in.p + (long)b * a.in.sB;
 
   f32x4 xr[XPIECES];
   u32x4 wr[WPIECES];
@@ -103,34 +85,25 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const ConvArgs a) {
     }
     return (long)cc * CK;
   };
-  auto prefetch = [&](const Item& it, int s) {
+  auto prefetch = [&](int s) {
     const int cc = s / NG, tg = s - cc * NG;
     if (tg == 0) {
-      const float* src = a.in.p + (long)it.b * a.in.sB + (long)(it.ty0 - PAD) * a.in.sY + (long)(it.tx0 - PAD) * a.in.sX +
-                         coff(cc);      // only dereferenced through in-image offsets
-      const bool interior = it.ty0 >= PAD && it.ty0 + 16 + PAD <= a.H && it.tx0 >= PAD && it.tx0 + 16 + PAD <= a.W &&
-                            (cc + 1) * CK <= a.Cin;
-      if (interior) {
 #pragma unroll
-        for (int i = 0; i < XPIECES; ++i) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (i < XPIECES - 1 || tid + i * 256 < XTOT) v = *reinterpret_cast<const f32x4*>(src + xgo[i]);
-          xr[i] = v;
+      for (int i = 0; i < XPIECES; ++i) {
+        const int q = tid + i * 256;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q < XTOT) {
+          const int pix = q / XV, part = q - pix * XV;
+          const int ly = pix / TW, lx = pix - ly * TW;
+          const int iy = ty0 + ly - PAD, ix = tx0 + lx - PAD;
+          const int c = cc * CK + part * 4;
+          if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin)
+            v = *reinterpret_cast<const f32x4*>(inb + (long)iy * a.in.sY + (long)ix * a.in.sX + coff(cc) + part * 4);
         }
-      } else {
-#pragma unroll
-        for (int i = 0; i < XPIECES; ++i) {
-          const int iy = it.ty0 + (xyx[i] >> 16) - PAD, ix = it.tx0 + ((xyx[i] >> 8) & 255) - PAD;
-          const bool ok = (tid + i * 256 < XTOT) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W &&
-                          (cc * CK + (xyx[i] & 255)) < a.Cin;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (ok) v = *reinterpret_cast<const f32x4*>(src + xgo[i]);
-          xr[i] = v;
-        }
+        xr[i] = v;
       }
     }
-    const __bf16* wbase = reinterpret_cast<const __bf16*>(a.groups > 1 ? a.w_group[it.grp] : a.w);
-    const __bf16* wsrc = wbase + ((size_t)((size_t)it.ntile * nCC + cc) * NTAPS + (size_t)tg * TAPG) * (NT * CK);
+    const __bf16* wsrc = wbase + ((size_t)((size_t)ntile * nCC + cc) * NTAPS + (size_t)tg * TAPG) * (NT * CK);
 #pragma unroll
     for (int i = 0; i < WPIECES; ++i) {
       const int q = tid + i * 256;
@@ -174,56 +147,37 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const ConvArgs a) {
   }
   const int boff = r * ROWB + 16 * h;
 
-  const unsigned total = nPix * nNTall;
-  unsigned id = blockIdx.x;
-  Item cur = decode(id);
-  prefetch(cur, 0);
-  for (;;) {
-    const unsigned nid = id + gridDim.x;
-    const bool more = PERS && nid < total;
-    Item nxt = cur;
-    if (more) nxt = decode(nid);
+  acc_t acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[mt][j] = 0.f;
 
-    acc_t acc[MT];
+  prefetch(0);
+  for (int s = 0; s < NS; ++s) {
+    __syncthreads();
+    commit(s);
+    __syncthreads();
+    if (s + 1 < NS) prefetch(s + 1);
+    const int tg = s % NG;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int tl = 0; tl < TAPG; ++tl) {
+      const int tap = (TAPG == NTAPS) ? tl : (tg * TAPG + tl);
+      const int ty = tap / KS, tx = tap - ty * KS;
+      const int tapoff = (ty * TW + tx) * ROWB;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[mt][j] = 0.f;
-
-    for (int s = 0; s < NS; ++s) {
-      __syncthreads();
-      commit(s);
-      __syncthreads();
-      if (s + 1 < NS) prefetch(cur, s + 1);
-      else if (more) prefetch(nxt, 0);          // the next item's first chunk flies under this item's epilogue
-      const int tg = s % NG;
+      for (int sub = 0; sub < CK / 16; ++sub) {
+        const bf16x8 bw = *reinterpret_cast<const bf16x8*>(ws + tl * (NT * ROWB) + boff + 32 * sub);
 #pragma unroll
-      for (int tl = 0; tl < TAPG; ++tl) {
-        const int tap = (TAPG == NTAPS) ? tl : (tg * TAPG + tl);
-        const int ty = tap / KS, tx = tap - ty * KS;
-        const int tapoff = (ty * TW + tx) * ROWB;
-#pragma unroll
-        for (int sub = 0; sub < CK / 16; ++sub) {
-          const bf16x8 bw = *reinterpret_cast<const bf16x8*>(ws + tl * (NT * ROWB) + boff + 32 * sub);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const bf16x8 ax = *reinterpret_cast<const bf16x8*>(xs + apix[mt] + tapoff + 32 * sub);
-            // weight fragment first: D[channel][pixel], the layout the shared epilogue expects
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, ax, acc[mt], 0, 0, 0);
-          }
+        for (int mt = 0; mt < MT; ++mt) {
+          const bf16x8 ax = *reinterpret_cast<const bf16x8*>(xs + apix[mt] + tapoff + 32 * sub);
+          // weight fragment first: D[channel][pixel], the layout the shared epilogue expects
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, ax, acc[mt], 0, 0, 0);
         }
       }
     }
-    {
-      const int b = cur.b, ty0 = cur.ty0, tx0 = cur.tx0;
-      const int n0 = cur.ntile * NT;
-      const long out_goff = a.groups > 1 ? a.out_group_off[cur.grp] : 0;
-#include "igemm_epilogue.inc"
-    }
-    if (!more) break;
-    id = nid;
-    cur = nxt;
   }
+#include "igemm_epilogue.inc"
 }
 
 // ---------------------------------------------------------------------------
@@ -486,27 +440,14 @@ static int launch_bf16(const ConvArgs& a, hipStream_t st) {
   constexpr size_t lds = lds_k > lds_e ? lds_k : lds_e;
   static DgOncePerDevice once;
   if (once.need()) {
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<KS, TAPG, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<KS, TAPG, true>),
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<KS, TAPG>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   ConvArgs b = a;
   b.lgx = cdiv(a.W, 16) * cdiv(a.H, 16) * a.B;
   b.lgy = cdiv(a.Cout, 32) * (a.groups > 1 ? a.groups : 1);
   const long total = (long)b.lgx * b.lgy;
-  // persistent form from the first item beyond what is resident (two workgroups per CU): every workgroup of the grid
-  // must be resident.  DEPGAN_BF16_PERSIST=0 keeps one item per workgroup (A/B runs).
-  static int pers = -1;
-  if (pers < 0) {
-    const char* e = getenv("DEPGAN_BF16_PERSIST");
-    pers = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  const long cap = 2L * dg_cu_count();
-  if (pers && total > cap)
-    hipLaunchKernelGGL((igemm_bf16_kernel<KS, TAPG, true>), dim3((unsigned)cap), dim3(256), lds, st, b);
-  else
-    hipLaunchKernelGGL((igemm_bf16_kernel<KS, TAPG, false>), dim3((unsigned)total), dim3(256), lds, st, b);
+  hipLaunchKernelGGL((igemm_bf16_kernel<KS, TAPG>), dim3((unsigned)total), dim3(256), lds, st, b);
   HIPCHECK(hipGetLastError());
   return DG_OK;
 }

@@ -115,8 +115,7 @@ BF16_CASES = [  # B,H,W,Cin,Cout,k: every variant of igemm_bf16.hip, ragged tile
     (2, 32, 32, 32, 32, 3), (2, 48, 40, 32, 64, 3), (1, 32, 32, 224, 96, 3), (2, 21, 19, 64, 160, 3),
     (2, 32, 32, 16, 32, 5), (2, 32, 32, 32, 32, 5), (2, 17, 33, 32, 64, 5), (2, 32, 32, 128, 128, 1),
     (2, 32, 32, 48, 96, 3), (1, 16, 16, 256, 256, 3), (2, 30, 18, 8, 32, 3), (2, 32, 32, 384, 96, 1),
-    # more items than resident workgroups (two per CU): the persistent form -- several items per workgroup, the next
-    # item's first chunk requested under the current item's epilogue; ragged tiles and a channel tail among them
+    # launches of a thousand and more workgroups; ragged tiles and a channel tail among them
     (9, 112, 120, 32, 64, 3), (6, 96, 104, 40, 32, 5), (16, 64, 64, 64, 96, 1),
 ]
 
