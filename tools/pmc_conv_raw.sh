@@ -1,6 +1,7 @@
 #!/bin/bash
 # Development aid: raw SQ / SQC counters of the MFMA conv kernel for one shape (tools/pmc_one_conv.py), averaged over
 # its dispatches, one rocprofv3 pass per counter group.  usage: bash tools/pmc_conv_raw.sh "32 256 256 32 32 3" [tag]
+# (CONV_PATH=3 in the environment selects the bf16 kernel, 7 the wave-private one: depgan_op_conv2d's path argument)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 SH="$1"; TAG="${2:-raw}"
 G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM"
@@ -19,7 +20,7 @@ for i in (1, 2, 3, 4):
     acc = collections.defaultdict(float); disp = collections.defaultdict(set)
     for f in glob.glob("gpurun_out/%s%d/**/*counter_collection.csv" % (tag, i), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "igemm_conv_kernel" in r["Kernel_Name"]:
+            if "igemm_conv_kernel" in r["Kernel_Name"] or "igemm_bf16_kernel" in r["Kernel_Name"] or "igemm_wp_kernel" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]] += float(r["Counter_Value"]); disp[r["Counter_Name"]].add(r["Dispatch_Id"])
     for k in sorted(acc):
         print("pass %d  %-32s per dispatch %16.0f   (%d dispatches)" % (i, k, acc[k] / max(len(disp[k]), 1), len(disp[k])))
