@@ -245,6 +245,8 @@ int dg_conv_igemm_wp(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
   // (a super-tile count that is not a multiple of 8 takes the plain id -> (super-tile, channel tile) form, in which a
   // persistent workgroup would change its channel tile: one item per workgroup then -- unit tests only)
   if (G > total || (a.lgx & 7) != 0) G = total;
+#ifdef DEPGAN_WP_ABLATIONS
+  // tools/ab_wp_ablation.sh (build with -DDEPGAN_WP_ABLATIONS): DEPGAN_WP_ABL selects an ablated instantiation
   static int abl = -1;
   if (abl < 0) {
     const char* e = getenv("DEPGAN_WP_ABL");
@@ -267,6 +269,7 @@ int dg_conv_igemm_wp(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
     HIPCHECK(hipGetLastError());
     return DG_OK;
   }
+#endif
   hipLaunchKernelGGL((igemm_wp_kernel<0>), dim3((unsigned)G), dim3(WP_NW * 64), lds, st, a);
   HIPCHECK(hipGetLastError());
   return DG_OK;

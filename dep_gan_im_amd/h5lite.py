@@ -21,8 +21,6 @@ tests/test_data_cpu.py reads files written by the real HDF5 library through h5py
 """
 from __future__ import annotations
 
-import struct
-
 import numpy as np
 
 SIGNATURE = b"\x89HDF\r\n\x1a\n"
