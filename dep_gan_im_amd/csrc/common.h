@@ -64,6 +64,14 @@ struct Epilogue {
   // igemm only: when pool.p is non-null the 2x2 / stride-2 max-pool of the final output is written here as well
   // (view of (H/2, W/2) pixels; H and W must be even).  Saves the pooling pass its read of the whole output.
   TView pool;
+  // igemm, 32-channel layers only (the 8-channel-chunk 3x3 kernel): when head_out is non-null the 1x1 convolution to ONE
+  // channel that follows (gen_segmentation after gen_17, GT:494-495) rides in this launch: head_out[pixel] =
+  // act(sum_c out[pixel][c] head_w[c] + head_b[0]), act = tanh when head_tanh.  head_skip_out: the 32-channel output
+  // itself is not stored (forward-only passes, where the head is its only consumer).
+  const float* head_w;
+  const float* head_b;
+  float* head_out;
+  int head_tanh, head_skip_out;
 };
 
 struct ConvArgs {
@@ -235,6 +243,8 @@ int dg_conv_igemm(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
 bool dg_conv_igemm_wp_supported(const ConvPlan& pl, const ConvArgs& a, bool force);
 int dg_conv_igemm_wp(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
 int dg_conv_igemm_tile(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
+// the launch for (pl, a) can carry the fused one-channel head (Epilogue::head_*): 32 -> 32, 8-channel-chunk 3x3 kernel
+bool dg_conv_igemm_head_supported(const ConvPlan& pl, const ConvArgs& a);
 // name of the kernel instantiation dg_conv_igemm launches for (pl, a), as rocprofv3 prints it
 void dg_conv_igemm_name(const ConvPlan& pl, const ConvArgs& a, char* buf, size_t cap);
 int dg_conv_direct(int KS, const ConvArgs& a, hipStream_t st);

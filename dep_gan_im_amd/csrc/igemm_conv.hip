@@ -66,8 +66,10 @@ struct Mfma<16> {
 // separate instantiations on purpose: in the looping form the compiler hoists the per-thread staging geometry out of
 // the loop (that is the point), which costs ~36 VGPRs and one resident workgroup per CU -- wrong for launches that
 // run one item per workgroup.
-template <int MF, int KS, int CK, int TAPG, bool PERS>
-__global__ __launch_bounds__(256, (PERS && KS == 3) ? (CK == 8 ? 4 : 3) : 1) void igemm_conv_kernel(const ConvArgs a) {
+// HEAD: the epilogue carries the fused one-channel 1x1 head (Epilogue::head_*); its own __global__ wrapper below so
+// that the plain instantiations keep their code and their names in the profiles.
+template <int MF, int KS, int CK, int TAPG, bool PERS, bool HEAD>
+static __device__ __forceinline__ void igemm_conv_body(const ConvArgs& a) {
   constexpr int NT = MF;
   constexpr int PAD = KS / 2;
   constexpr int TW = 16 + KS - 1;
@@ -335,13 +337,26 @@ __global__ __launch_bounds__(256, (PERS && KS == 3) ? (CK == 8 ? 4 : 3) : 1) voi
   }
 
   if (dbg && tid == 0) dbg[4] = __builtin_amdgcn_s_memtime();
+#define EPI_HEAD HEAD
 #include "igemm_epilogue.inc"
+#undef EPI_HEAD
   if (dbg && tid == 0) {
     dbg[5] = __builtin_amdgcn_s_memtime();
     dbg[6] = __builtin_amdgcn_s_memrealtime() - dbg[6];
   }
   dbg = nullptr;   // stamps describe the first item only
   } while (PERS && (id += gridDim.x) < nPix * nNTall);
+}
+
+template <int MF, int KS, int CK, int TAPG, bool PERS>
+__global__ __launch_bounds__(256, (PERS && KS == 3) ? (CK == 8 ? 4 : 3) : 1) void igemm_conv_kernel(const ConvArgs a) {
+  igemm_conv_body<MF, KS, CK, TAPG, PERS, false>(a);
+}
+
+// gen_17 + gen_segmentation in one launch (32 -> 32 3x3, then 32 -> 1 and tanh): the 8-channel-chunk kernel
+template <bool PERS>
+__global__ __launch_bounds__(256, PERS ? 4 : 1) void igemm_conv_head_kernel(const ConvArgs a) {
+  igemm_conv_body<32, 3, 8, 9, PERS, true>(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -436,9 +451,31 @@ static int launch_variant(const ConvArgs& a, hipStream_t st, char* name_out = nu
   b.lgy = cdiv(a.Cout, MF) * (a.groups > 1 ? a.groups : 1);
   const long total = (long)b.lgx * b.lgy;
   const long G = igemm_grid(KS, CK, lds, total);
+  constexpr bool CAN_HEAD = (MF == 32 && KS == 3 && CK == 8 && TAPG == 9);
+  const bool head = a.ep.head_out != nullptr;
+  if (head && (!CAN_HEAD || a.Cout != 32 || a.groups > 1 || a.ep.pool.p != nullptr)) {
+    dg_set_error("dg_conv_igemm: the fused head needs the 8-channel-chunk 3x3 kernel and 32 output channels");
+    return DG_ERR_ARG;
+  }
   if (name_out) {
-    snprintf(name_out, name_cap, "igemm_conv_kernel<%d,%d,%d,%d,%s>", MF, KS, CK, TAPG, G < total ? "true" : "false");
+    if (head) snprintf(name_out, name_cap, "igemm_conv_head_kernel<%s>", G < total ? "true" : "false");
+    else snprintf(name_out, name_cap, "igemm_conv_kernel<%d,%d,%d,%d,%s>", MF, KS, CK, TAPG, G < total ? "true" : "false");
     return DG_OK;
+  }
+  if constexpr (CAN_HEAD) {
+    if (head) {
+      static DgOncePerDevice once_h;
+      if (once_h.need()) {
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_head_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_head_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      }
+      if (G < total) hipLaunchKernelGGL((igemm_conv_head_kernel<true>), dim3((unsigned)G), dim3(256), lds, st, b);
+      else hipLaunchKernelGGL((igemm_conv_head_kernel<false>), dim3((unsigned)G), dim3(256), lds, st, b);
+      HIPCHECK(hipGetLastError());
+      return DG_OK;
+    }
   }
   // the dynamic-LDS attribute is per device: a process may hold contexts on several GPUs (Engine(device=...))
   static DgOncePerDevice once;
@@ -468,6 +505,11 @@ static int dispatch_variant(const ConvPlan& pl, const ConvArgs& a, hipStream_t s
   }
   dg_set_error("dg_conv_igemm: bad variant %d", pl.variant);
   return DG_ERR_ARG;
+}
+
+bool dg_conv_igemm_head_supported(const ConvPlan& pl, const ConvArgs& a) {
+  return pl.variant == 8 && !pl.bf16 && a.Cout == 32 && a.groups <= 1 && a.ep.pool.p == nullptr && a.cpt <= 0 &&
+         !a.ep.accumulate;
 }
 
 void dg_conv_igemm_name(const ConvPlan& pl, const ConvArgs& a, char* buf, size_t cap) {
@@ -505,6 +547,10 @@ static int conv_igemm_impl(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t
       dg_set_error("dg_conv_igemm: gathered K needs Cin = runs (<= 4) x cpt x %d channels and 16-byte run offsets", pl.CK);
       return DG_ERR_ARG;
     }
+  }
+  if (a.ep.head_out && !dg_conv_igemm_head_supported(pl, a)) {
+    dg_set_error("dg_conv_igemm: the fused head needs the fp32 8-channel-chunk 3x3 kernel, 32 output channels, no pool");
+    return DG_ERR_ARG;
   }
   if (is_bf16) return dg_conv_igemm_bf16(pl, a, st);
   if (allow_wp && dg_conv_igemm_wp_supported(pl, a, false)) return dg_conv_igemm_wp(pl, a, st);

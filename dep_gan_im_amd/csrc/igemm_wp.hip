@@ -213,6 +213,7 @@ __global__ __launch_bounds__(WP_NW * 64, 1) void igemm_wp_kernel(const ConvArgs 
 bool dg_conv_igemm_wp_supported(const ConvPlan& pl, const ConvArgs& a, bool force) {
   if (pl.variant != 8 || pl.bf16 || pl.KS != 3 || pl.CK != WP_CK) return false;
   if (a.Cin != pl.Cin || (a.Cin % WP_CK) || a.Cin > 64 || (a.Cout % 32) || a.groups > 1 || a.cpt > 0 || a.dbg) return false;
+  if (a.ep.head_out) return false;   // the fused head lives in the tile kernel's epilogue only
   const size_t lds = ((size_t)a.Cin * 9 * 32 + (size_t)WP_NW * WP_WAVE_FLOATS) * sizeof(float);
   if (lds > 160 * 1024) return false;
   if (force) return true;

@@ -125,8 +125,9 @@ int conv_launch(depgan_ctx* c, const ConvPlan& pl, const ConvArgs& a, int KS) {
   const double px = 4.0 * a.B * a.H * a.W;
   const double by = px * a.Cin + ng * (px * a.Cout * (1 + (a.ep.res.p ? 1 : 0) + (a.ep.mask.p ? 1 : 0) +
                                                       (a.ep.out_pre.p ? 1 : 0) + (a.ep.accumulate ? 1 : 0) +
-                                                      (a.ep.pool.p ? 0.25 : 0)) +
-                                          4.0 * KS * KS * a.Cin * a.Cout);
+                                                      (a.ep.pool.p ? 0.25 : 0) - (a.ep.head_skip_out ? 1 : 0)) +
+                                          4.0 * KS * KS * a.Cin * a.Cout) +
+                    (a.ep.head_out ? px + 4.0 * a.Cout : 0.0);
   if (pl.variant >= 0) {
     char kn[48] = "";
     if (c->prof_on) dg_conv_igemm_name(pl, a, kn, sizeof(kn));
@@ -771,7 +772,7 @@ int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u
     ProfScope ps(c, 2, 0.0, "noise mlp fwd");
     DGCHECK(dg_noise_fwd(c->np, z, c->na, n, c->st));
   }
-  bool pooled_by_conv = false;
+  bool pooled_by_conv = false, head_by_conv = false;
   for (size_t i = 0; i < c->gl.size(); ++i) {
     GLayer& L = c->gl[i];
     if (L.kind == G_CONV || L.kind == G_FILM) {
@@ -800,6 +801,17 @@ int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u
         a.wsT = (long)L.Cin * L.Cout; a.wsI = L.Cout; a.wsO = 1; a.flip = 0;
       }
       pooled_by_conv = a.ep.pool.p != nullptr;
+      // gen_segmentation (1x1 to one channel, tanh: GT:494-495) rides in gen_17's epilogue where the layer runs on the
+      // 8-channel-chunk kernel; forward-only passes then do not store gen_17's own output at all
+      head_by_conv = false;
+      if (L.kind == G_CONV && i + 1 < c->gl.size() && c->gl[i + 1].kind == G_HEAD && c->cfg.nc_out == 1 &&
+          c->head_fused && dg_conv_igemm_head_supported(L.pf, a)) {
+        const GLayer& Hd = c->gl[i + 1];
+        a.ep.head_w = Hd.Wt; a.ep.head_b = Hd.b; a.ep.head_out = c->attr.p;
+        a.ep.head_tanh = 1;
+        a.ep.head_skip_out = (!store_u && !c->dbg_capture) ? 1 : 0;
+        head_by_conv = true;
+      }
       DGCHECK(conv_launch(c, L.pf, a, 3));
     } else if (L.kind == G_POOL) {
       if (pooled_by_conv && L.skip_of == (int)i - 1) continue;
@@ -827,6 +839,7 @@ int g_forward(depgan_ctx* c, const float* x, const float* z, int n, bool store_u
       a.w = L.wpf[0];
       DGCHECK(conv_launch(c, L.pf, a, 1));
     } else if (L.kind == G_HEAD && c->cfg.nc_out == 1) {
+      if (head_by_conv) continue;
       ProfScope ps(c, 2, 0.0, "head fwd");
       DGCHECK(dg_head_fwd(L.in.p, L.Wt, L.b, c->attr.p, (long)n * L.H * L.W, L.Cin, 1, c->st));
     }
@@ -1303,6 +1316,10 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
     // -- the A/B switch of tests/test_gpu_model.py::test_config4_bf16_matrix_pipe
     const char* e = getenv("DEPGAN_WGRAD_BF16");
     c->wgrad_bf16 = !(e && atoi(e) == 0);
+    // same pattern: DEPGAN_HEAD_FUSED=0 keeps gen_segmentation in its own launch (the A/B switch of
+    // tests/test_gpu_model.py::test_fused_head_matches_the_separate_launch)
+    const char* hf = getenv("DEPGAN_HEAD_FUSED");
+    c->head_fused = !(hf && atoi(hf) == 0);
   }
   if (c->cfg.nc_out <= 0) c->cfg.nc_out = 1;
   if (c->cfg.nc_out != 1 && c->cfg.nc_out != 4) {

@@ -54,6 +54,52 @@ def _engine(img, B, PG, PD1, PD2, **kw):
 SPLIT = pytest.mark.parametrize("split", [0, 6], ids=["native", "split6"])
 
 
+def test_fused_head_matches_the_separate_launch(lib, tmp_path):
+    """gen_segmentation (1x1 to one channel + tanh, GT:494-495) rides in gen_17's convolution epilogue at full size
+    (igemm_conv_head_kernel).  A/B against the same library with DEPGAN_HEAD_FUSED=0 (the separate dg_head_fwd launch)
+    on the same weights and inputs: the 32-channel activation bit for bit, the head's output to summation order, the
+    forward-only pass (which no longer stores gen_17's activation) equal to the training pass, generator gradients
+    through the stored activation to summation order -- and the profile shows which kernel ran."""
+    from oracle import depgan_oracle as O
+    img, B = 256, 3                                   # 3: an item count the persistent grid does not divide
+    PG, PD1, PD2, x, y2, z, ep = _setup(img, B, 77, noisy=True)
+    want = O.g_predict(PG, x, z)
+
+    def run(fused):
+        os.environ["DEPGAN_HEAD_FUSED"] = "1" if fused else "0"
+        try:
+            eng = _engine(img, B, PG, PD1, PD2)
+        finally:
+            del os.environ["DEPGAN_HEAD_FUSED"]
+        eng.profile(True)
+        fwd = eng.g_forward(x, z).cpu().numpy()
+        eng.profile(False)
+        csv = str(tmp_path / ("prof_%d.csv" % fused))
+        eng.profile_dump(csv)
+        kernels = open(csv).read()
+        eng.debug_capture(True)
+        eng.generator(x, y2, z, "grads")
+        act = eng.debug_tensor("g/out/gen_17")
+        attr_train = eng.g_forward(x, z).cpu().numpy()    # capture on: the activation is stored, same launch otherwise
+        eng.debug_capture(False)
+        g = eng.get_grads("G")
+        eng.close()
+        return fwd, kernels, act, attr_train, g
+
+    f1, k1, a1, t1, g1 = run(True)
+    f0, k0, a0, t0, g0 = run(False)
+    assert "igemm_conv_head_kernel" in k1 and "head fwd" not in k1, k1
+    assert "igemm_conv_head_kernel" not in k0 and "head fwd" in k0, k0
+    assert np.array_equal(a1, a0)                       # the convolution itself is the same arithmetic
+    assert np.array_equal(f1, t1)                       # with and without the activation store
+    d = float(np.abs(f1 - f0).max())
+    print("fused head vs separate launch: max |diff| %.2e; vs oracle %.2e / %.2e" % (d, rel(f1, want), rel(f0, want)))
+    assert d < 2e-6 and rel(f1, want) < 1e-4
+    worst = max(float(np.abs(g1[k] - g0[k]).max() / (np.abs(g0[k]).max() + 1e-30)) for k in g0)
+    print("fused head: generator gradients vs separate launch, worst tensor %.2e" % worst)
+    assert worst < 1e-4
+
+
 @SPLIT
 @pytest.mark.parametrize("name", ["small_64_b2", "full_256_b2"])
 def test_forward_and_eval_match_golden(lib, name, split):

@@ -1,9 +1,9 @@
-"""Prints the headline and the per-config summaries of a bench.py result file.  usage: python tools/show_bench.py <file>"""
+"""Prints the headline and the per-config summaries of a bench.py result file.  usage: python tools/show_bench.py [file]   (no file: stdin)"""
 import json
 import sys
 
 d = None
-for ln in open(sys.argv[1]):
+for ln in (open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin):
     if ln.startswith("{"):
         d = json.loads(ln)
 print("headline: %.1f slices/s, %.3f ms per step" % (d["value"], d["ms_per_step"]))
