@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdepgan.so")
-SOURCES = ["igemm_conv.hip", "igemm_wp.hip", "igemm_bf16.hip", "deconv_fwd.hip", "deconv_wgrad.hip", "wgrad.hip", "wgrad_bf16.hip", "direct.hip", "ops.hip", "noise.hip", "train_ops.hip", "model.hip",
+SOURCES = ["igemm_conv.hip", "igemm_wp.hip", "igemm_wino.hip", "igemm_bf16.hip", "deconv_fwd.hip", "deconv_wgrad.hip", "wgrad.hip", "wgrad_bf16.hip", "direct.hip", "ops.hip", "noise.hip", "train_ops.hip", "model.hip",
            "uresnet.hip", "data.hip"]
 ARCH = "gfx950"
 

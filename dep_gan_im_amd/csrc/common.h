@@ -219,6 +219,7 @@ struct PackJob {
   int bf16;             // 1: dst is a bf16 panel (elements of 2 bytes, RNE from the fp32 source x kscale); 2 / 3: split
                         // panel of that many planes (plane p = bf16 of what planes < p left over), TAPG taps per group
   int tapg;             // split panels only: taps per staged group
+  int wino;             // 1: Winograd panel -- ntaps = 16 "frequencies" f = 4a + b, element = (G g G^T)[a][b] of the 3x3 source
   unsigned total;       // packed elements of this job
   unsigned per_nt;      // packed floats per channel tile (nCC * ntaps * NT * CK)
   unsigned nt_stride;   // destination elements between channel tiles
@@ -245,6 +246,11 @@ int dg_conv_igemm_wp(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
 int dg_conv_igemm_tile(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
 // the launch for (pl, a) can carry the fused one-channel head (Epilogue::head_*): 32 -> 32, 8-channel-chunk 3x3 kernel
 bool dg_conv_igemm_head_supported(const ConvPlan& pl, const ConvArgs& a);
+// Winograd F(2x2,3x3) kernel (igemm_wino.hip): plan variant 9, panel [nt][chunk][16 frequencies][32][8] of G g G^T
+ConvPlan dg_plan_conv_wino(int Cin, int Cout);
+bool dg_conv_wino_supported(const ConvPlan& pl, const ConvArgs& a);
+const char* dg_conv_wino_name(const ConvArgs& a);
+int dg_conv_wino(const ConvPlan& pl, const ConvArgs& a, hipStream_t st);
 // name of the kernel instantiation dg_conv_igemm launches for (pl, a), as rocprofv3 prints it
 void dg_conv_igemm_name(const ConvPlan& pl, const ConvArgs& a, char* buf, size_t cap);
 int dg_conv_direct(int KS, const ConvArgs& a, hipStream_t st);

@@ -417,6 +417,17 @@ ConvPlan dg_plan_conv_items(int KS, int Cin, int Cout, long items) {
   return p;
 }
 
+// Winograd F(2x2,3x3) plan (igemm_wino.hip): 8-channel chunks, 16 transform-domain panels per chunk
+ConvPlan dg_plan_conv_wino(int Cin, int Cout) {
+  ConvPlan p = dg_plan_conv(3, Cin, Cout);
+  if (p.variant != 0 || (Cin % 8) != 0 || (Cout % 32) != 0) { p.variant = -1; return p; }
+  p.variant = 9;
+  p.CK = 8;
+  p.nCC = Cin / 8;
+  p.packedFloats = (size_t)p.nNT * p.nCC * 16 * p.NT * p.CK;
+  return p;
+}
+
 // Persistent workgroups: as many as are resident per CU (3 by registers, fewer where the LDS tile is large), each
 // walking ~total / G items.  The per-thread staging geometry and address arithmetic (about 550 instructions per
 // item) is then computed once per workgroup.  Every workgroup of the grid MUST be resident: one that has to wait
@@ -508,7 +519,7 @@ static int dispatch_variant(const ConvPlan& pl, const ConvArgs& a, hipStream_t s
 }
 
 bool dg_conv_igemm_head_supported(const ConvPlan& pl, const ConvArgs& a) {
-  return pl.variant == 8 && !pl.bf16 && a.Cout == 32 && a.groups <= 1 && a.ep.pool.p == nullptr && a.cpt <= 0 &&
+  return (pl.variant == 8 || pl.variant == 9) && !pl.bf16 && a.Cout == 32 && a.groups <= 1 && a.ep.pool.p == nullptr && a.cpt <= 0 &&
          !a.ep.accumulate;
 }
 
@@ -516,6 +527,7 @@ void dg_conv_igemm_name(const ConvPlan& pl, const ConvArgs& a, char* buf, size_t
   if (cap) buf[0] = 0;
   if (pl.variant < 0) { snprintf(buf, cap, "conv_direct"); return; }
   if (pl.bf16) { snprintf(buf, cap, pl.variant >= 200 ? "igemm_split_kernel" : "igemm_bf16_kernel"); return; }
+  if (pl.variant == 9) { snprintf(buf, cap, "%s", dg_conv_wino_name(a)); return; }
   if (dg_conv_igemm_wp_supported(pl, a, false)) { snprintf(buf, cap, "igemm_wp_kernel<0>"); return; }
   dispatch_variant(pl, a, nullptr, buf, cap);
 }
@@ -553,6 +565,7 @@ static int conv_igemm_impl(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t
     return DG_ERR_ARG;
   }
   if (is_bf16) return dg_conv_igemm_bf16(pl, a, st);
+  if (pl.variant == 9) return dg_conv_wino(pl, a, st);   // its panel fits no other kernel
   if (allow_wp && dg_conv_igemm_wp_supported(pl, a, false)) return dg_conv_igemm_wp(pl, a, st);
   return dispatch_variant(pl, a, st, nullptr, 0);
 }
@@ -592,6 +605,31 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+// Element f = 4a + b of the Winograd weight transform U = G g G^T of one (input channel, output channel) pair, G =
+// [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: the (up to nine) terms in double, rounded to fp32 once.  g is what the direct
+// kernel multiplies with: the fp32 source element (x kscale, rounded to fp32 as the plain panel stores it).
+static __device__ __forceinline__ float wino_weight(const float* __restrict__ e0, size_t tap_stride, int f, int flip,
+                                                     float ks, bool has_ks) {
+  const int a = f >> 2, b = f & 3;
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double ga = (a == 0) ? (i == 0 ? 1.0 : 0.0) : (a == 3) ? (i == 2 ? 1.0 : 0.0) : ((a == 2 && i == 1) ? -0.5 : 0.5);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double gb = (b == 0) ? (j == 0 ? 1.0 : 0.0) : (b == 3) ? (j == 2 ? 1.0 : 0.0) : ((b == 2 && j == 1) ? -0.5 : 0.5);
+      const double cf = ga * gb;
+      if (cf != 0.0) {
+        const int t = 3 * i + j, ts = flip ? 8 - t : t;
+        float g = e0[(size_t)ts * tap_stride];
+        if (has_ks) g *= ks;
+        s += cf * (double)g;
+      }
+    }
+  }
+  return (float)s;
+}
+
 // Batched form: every packed panel of a network in ONE launch (a refresh after an Adam step used to be ~130 launches
 // of a few microseconds each for the generator).  Block -> job by binary search over the jobs' first blocks.
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
@@ -617,10 +655,15 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackJob* 
     if (kk < J.Kdim && nn < J.Ndim) {
       const int ci = J.transpose ? nn : kk;
       const int co = J.transpose ? kk : nn;
-      const int ts = J.flip ? (J.ntaps - 1 - tap) : tap;
-      const size_t off = (size_t)ts * J.srcI * J.srcO + (J.io ? ((size_t)co * J.srcI + ci) : ((size_t)ci * J.srcO + co));
-      v = J.src[off];
-      if (J.kscale) v *= J.kscale[kk];
+      const size_t eo = J.io ? ((size_t)co * J.srcI + ci) : ((size_t)ci * J.srcO + co);
+      const size_t ts_stride = (size_t)J.srcI * J.srcO;
+      if (J.wino) {
+        v = wino_weight(J.src + eo, ts_stride, tap, J.flip, J.kscale ? J.kscale[kk] : 1.f, J.kscale != nullptr);
+      } else {
+        const int ts = J.flip ? (J.ntaps - 1 - tap) : tap;
+        v = J.src[(size_t)ts * ts_stride + eo];
+        if (J.kscale) v *= J.kscale[kk];
+      }
     }
     if (J.bf16 >= 2)
       store_split(J.dst, (size_t)nt * J.nt_stride * J.bf16, cc, tap, n, k, v, J.bf16, J.tapg, J.ntaps, J.NT, J.CK);
@@ -637,12 +680,13 @@ int dg_pack_job(const ConvPlan& pl, const float* src, int srcI, int srcO, int io
     return DG_ERR_ARG;
   }
   job->src = src; job->dst = dst; job->kscale = kscale;
-  job->ntaps = pl.KS * pl.KS; job->srcI = srcI; job->srcO = srcO; job->io = io; job->transpose = transpose;
+  job->wino = (pl.variant == 9) ? 1 : 0;
+  job->ntaps = job->wino ? 16 : pl.KS * pl.KS; job->srcI = srcI; job->srcO = srcO; job->io = io; job->transpose = transpose;
   job->flip = flip; job->NT = pl.NT; job->CK = pl.CK; job->nCC = pl.nCC; job->Kdim = Kdim; job->Ndim = Ndim;
   job->bf16 = pl.bf16;
   job->tapg = (pl.variant >= 200) ? (pl.KS == 5 ? 5 : pl.KS * pl.KS) : 0;
-  job->total = (unsigned)((size_t)pl.nNT * pl.nCC * pl.KS * pl.KS * pl.NT * pl.CK);
-  job->per_nt = (unsigned)((size_t)pl.nCC * pl.KS * pl.KS * pl.NT * pl.CK);
+  job->total = (unsigned)((size_t)pl.nNT * pl.nCC * job->ntaps * pl.NT * pl.CK);
+  job->per_nt = (unsigned)((size_t)pl.nCC * job->ntaps * pl.NT * pl.CK);
   job->nt_stride = nt_stride ? (unsigned)nt_stride : job->per_nt;
   job->blk0 = job->nblk = 0;
   return DG_OK;
@@ -674,6 +718,18 @@ int dg_pack_weights(const ConvPlan& pl, const float* src, int srcI, int srcO, in
   if (Kdim != pl.Cin || Ndim != pl.Cout) {
     dg_set_error("dg_pack_weights: plan (%d->%d) does not match source roles (%d->%d)", pl.Cin, pl.Cout, Kdim, Ndim);
     return DG_ERR_ARG;
+  }
+  if (pl.variant == 9) {   // Winograd panels exist in the batched kernel only: one job
+    PackJob job;
+    DGCHECK(dg_pack_job(pl, src, srcI, srcO, io, transpose, flip, kscale, dst, 0, &job));
+    const unsigned nb = dg_pack_layout(&job, 1);
+    PackJob* jd = nullptr;
+    HIPCHECK(hipMalloc((void**)&jd, sizeof(PackJob)));
+    hipError_t e = hipMemcpyAsync(jd, &job, sizeof(PackJob), hipMemcpyHostToDevice, st);
+    int rc = (e == hipSuccess) ? dg_pack_weights_batch(jd, 1, nb, st) : DG_ERR_HIP;
+    hipStreamSynchronize(st);   // `job` lives on this stack frame
+    hipFree(jd);
+    return rc;
   }
   const size_t total = (size_t)pl.nNT * pl.nCC * pl.KS * pl.KS * pl.NT * pl.CK;
   const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);

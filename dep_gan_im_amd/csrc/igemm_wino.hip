@@ -1,0 +1,362 @@
+// 3x3 NHWC fp32 convolution as Winograd F(2x2, 3x3) on the CDNA4 fp32 matrix cores: 16 multiplications per 2x2 output
+// block and input channel instead of 36 -- the contraction of igemm_conv_kernel<32,3,8,9> with 4/9 of its MFMAs.
+//
+// Why: on this machine an fp32 MFMA stream is the vector ALU (nothing a SIMD issues overlaps with
+// it), igemm_conv_kernel sits at 0.68 ... 0.84 of the fp32 matrix peak on the 3x3 layers and its ablations
+// (profiles/r03_conv_experiments.md) put 0.82 as the ceiling of ANY direct form.  The remaining lever is the number of
+// MFMAs.  Y = A^T [ (G g G^T) . (B^T d B) ] A with the usual F(2x2,3x3) matrices: B^T and A^T hold only 0 and +-1 (the
+// input and output transforms are additions), G holds 1 and 1/2 (the weight transform is done once per weight update by
+// the packing kernel, in double, rounded once).  Same operands, same fp32 accumulation over Cin in the same chunk order;
+// what changes is the summation tree (measured against an fp64 convolution: 1.7 x the rounding error of the direct
+// kernel, both ~1e-7 of the output's range -- tests/test_gpu_ops.py).
+//
+// Mapping (one workgroup = 256 threads = 4 waves; item = 16 x 16 output pixels of one sample x 32 output channels):
+//   * the 16 x 16 tile is 8 x 8 = 64 Winograd tiles; the 16 "frequencies" (a, b) of the transform domain are 16
+//     independent GEMMs  M_f[tile][n] = sum_c V_f[tile][c] U_f[c][n]  (64 x Cin x 32);
+//   * wave w owns the frequencies a = w (b = 0..3): 4 frequencies x 2 MFMA row tiles (32 tiles each) of
+//     v_mfma_f32_32x32x2_f32 = 8 accumulators = 128 registers.  Its weight fragments U_f are nobody else's: they go
+//     from the packed panel [nt][chunk][f][n][8] straight into registers, never through LDS;
+//   * per chunk of 8 input channels: the 18 x 18 x 8 raw halo goes global -> registers -> LDS (as in igemm_conv), every
+//     thread transforms 2 x (tile, 4 channels, a) to four b128 rows of V[f][tile][8] in LDS (16 packed additions each),
+//     barrier, 32 MFMAs per wave with one b128 A-fragment read per 4 of them;
+//   * epilogue: each wave reduces its four b's to the two output columns in registers (Z[a][q] = row transform), the
+//     waves exchange Z through LDS, and the fused epilogue of igemm_conv (igemm_epilogue.inc, same text) fetches
+//     v = Z[0] + Z[1] + Z[2] (even rows) or Z[1] - Z[2] - Z[3] (odd rows) where it used to fetch one transposed value.
+// Covers KS = 3, stride 1, 'same' padding, Cin % 8 == 0, Cout % 32 == 0, even H and W; gathered K (ConvArgs::cpt) as in
+// igemm_conv; no groups.  Everything else stays on igemm_conv_kernel.
+#include <stdlib.h>
+
+#include "common.h"
+#include "epilogue.h"
+
+namespace {
+
+constexpr int WN_CK = 8, WN_CKP = 12;           // channels per chunk; floats per raw halo pixel (48 B rows)
+constexpr int WN_TW = 18, WN_PIXT = WN_TW * WN_TW;
+constexpr int WN_RAW = WN_PIXT * WN_CKP;        // 3888 floats
+constexpr int WN_VPLANE = 64 * WN_CK + 4;       // one frequency: 64 tiles x 8 channels, +16 B so that the four a's of a
+                                                // transform write (planes 4 apart) fall into different bank groups
+constexpr int WN_V = 16 * WN_VPLANE;            // 8256 floats
+constexpr int WN_CP = 36;                       // floats per tile row of the Z exchange (32 channels + 4)
+constexpr int WN_ZPLANE = 64 * WN_CP + 32;      // one (a, q): +128 B so that q = 0 / 1 of a pixel pair differ in bank group
+constexpr int WN_Z = 8 * WN_ZPLANE;             // 18688 floats
+constexpr int WN_XV = WN_CK / 4;
+constexpr int WN_XTOT = WN_PIXT * WN_XV;        // 648 16-byte pieces of a raw chunk
+constexpr int WN_XPIECES = (WN_XTOT + 255) / 256;
+constexpr size_t WN_LDS = sizeof(float) * (size_t)((WN_RAW + WN_V) > WN_Z ? (WN_RAW + WN_V) : WN_Z);
+
+// ABL: ablation bits for tools/time_wino.py (0 = the product kernel; the others are compiled with
+// -DDEPGAN_WINO_ABLATIONS only): 1 no epilogue, 2 no input transform, 4 no MFMAs, 8 no raw staging
+template <bool PERS, bool HEAD, int ABL = 0>
+static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
+  constexpr int MF = 32, NT = 32, MT = 2;
+  typedef f32x16 acc_t;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* raw = smem;            // [324][12]
+  float* V = smem + WN_RAW;     // [16][WN_VPLANE]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + 15) >> 4;
+  const unsigned nNTall = (unsigned)a.lgy, nPix = (unsigned)a.lgx;
+  const int nCC = a.Cin / WN_CK;
+
+  // ---- per-thread geometry, once per workgroup ----
+  // raw staging piece i: slot q = tid + 256 i -> halo pixel q / 2, channel half q & 1
+  unsigned xgb[WN_XPIECES], xlb[WN_XPIECES];
+  int xyx[WN_XPIECES];
+#pragma unroll
+  for (int i = 0; i < WN_XPIECES; ++i) {
+    const int q = min(tid + i * 256, WN_XTOT - 1);
+    const int pix = q / WN_XV, part = q - pix * WN_XV;
+    const int ly = pix / WN_TW, lx = pix - ly * WN_TW;
+    xgb[i] = 4u * (unsigned)(ly * (int)a.in.sY + lx * (int)a.in.sX + part * 4);
+    xlb[i] = 4u * (unsigned)(pix * WN_CKP + part * 4);
+    xyx[i] = (ly << 16) | (lx << 8) | (part * 4);
+  }
+  const bool in_last = tid < (WN_XTOT % 256);
+  // transform task i: q = tid + 256 i -> channel group q & 1, transform row a = (q >> 1) & 3, tile q >> 3.
+  // Row a of B^T d needs two of the tile's four halo rows:  a = 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3
+  // = x + s y with (x, y) = rows (0,2) (1,2) (2,1) (1,3) and s = +1 for a = 1, else -1.
+  int tA[2], tB[2], tV[2];
+  float tS[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = tid + 256 * i;
+    const int cg = q & 1, aa = (q >> 1) & 3, T = q >> 3;
+    const int tyi = T >> 3, txi = T & 7;
+    const int rA = (aa == 0) ? 0 : (aa == 2 ? 2 : 1), rB = (aa == 3) ? 3 : (aa == 2 ? 1 : 2);
+    tA[i] = ((2 * tyi + rA) * WN_TW + 2 * txi) * WN_CKP + 4 * cg;
+    tB[i] = ((2 * tyi + rB) * WN_TW + 2 * txi) * WN_CKP + 4 * cg;
+    tV[i] = (4 * aa) * WN_VPLANE + T * WN_CK + 4 * cg;
+    tS[i] = (aa == 1) ? 1.f : -1.f;
+  }
+  const unsigned rawb0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)raw;
+  // fragments: A = V[f][32 mt + r][4h ..], B = panel[f][r][4h ..]
+  const int aoff = r * WN_CK + 4 * h;
+  const int boff = (4 * wv * 32 + r) * WN_CK + 4 * h;
+
+  unsigned id = blockIdx.x;
+  do {
+    int t, ntile;
+    if ((nPix & 7u) == 0) {   // ids dealt over the 8 XCDs as in igemm_conv_kernel
+      const unsigned x = id & 7u, sl = id >> 3;
+      ntile = (int)(sl % nNTall);
+      t = (int)(x * (nPix >> 3) + sl / nNTall);
+    } else {
+      t = (int)(id % nPix);
+      ntile = (int)(id / nPix);
+    }
+    const int tx0 = (t % tilesX) * 16;
+    t /= tilesX;
+    const int ty0 = (t % tilesY) * 16;
+    const int b = t / tilesY;
+    const long out_goff = 0;
+    const int n0 = ntile * NT;
+    const float* inb = a.in.p + (long)b * a.in.sB;
+    const bool interior = ty0 >= 1 && ty0 + 17 <= a.H && tx0 >= 1 && tx0 + 17 <= a.W;
+    const char* halo0 = reinterpret_cast<const char*>(inb + ((long)(ty0 - 1) * a.in.sY + (long)(tx0 - 1) * a.in.sX));
+    auto coff = [&](int cc) -> long {
+      if (a.cpt > 0) {
+        const int run = cc / a.cpt;
+        return a.in_run_off[run] + (long)(cc - run * a.cpt) * WN_CK;
+      }
+      return (long)cc * WN_CK;
+    };
+    f32x4 xr[WN_XPIECES];
+    auto prefetch = [&](int cc) {
+      const char* src = halo0 + 4 * coff(cc);   // only dereferenced through in-image offsets
+      if (interior) {
+#pragma unroll
+        for (int i = 0; i < WN_XPIECES - 1; ++i) xr[i] = *reinterpret_cast<const f32x4*>(src + xgb[i]);
+        if (in_last) xr[WN_XPIECES - 1] = *reinterpret_cast<const f32x4*>(src + xgb[WN_XPIECES - 1]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < WN_XPIECES; ++i) {
+          const int iy = ty0 + (xyx[i] >> 16) - 1, ix = tx0 + ((xyx[i] >> 8) & 255) - 1;
+          const bool ok = (i < WN_XPIECES - 1 || in_last) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (ok) v = *reinterpret_cast<const f32x4*>(src + xgb[i]);
+          xr[i] = v;
+        }
+      }
+    };
+    auto commit = [&]() {
+#pragma unroll
+      for (int i = 0; i < WN_XPIECES - 1; ++i)
+        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((size_t)(rawb0 + xlb[i])) = xr[i];
+      if (in_last)
+        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((size_t)(rawb0 + xlb[WN_XPIECES - 1])) =
+            xr[WN_XPIECES - 1];
+    };
+
+    acc_t acc[4][MT];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[f][mt][j] = 0.f;
+
+    const float* wnt = a.w + (size_t)ntile * nCC * (16 * NT * WN_CK) + boff;
+    if (!(ABL & 8)) prefetch(0);
+    for (int cc = 0; cc < nCC; ++cc) {
+      // this wave's weight fragments of the chunk: four frequencies x (32 channels x 8) -- in flight during the transform
+      f32x4 bq[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        bq[f] = *reinterpret_cast<const f32x4*>(wnt + (size_t)cc * (16 * NT * WN_CK) + f * (NT * WN_CK));
+      // every wave is past the barrier that followed the previous transform: the raw tile is free
+      if (!(ABL & 8)) commit();
+      __syncthreads();   // raw chunk cc complete; every wave is done with the MFMAs that read V of chunk cc - 1
+      if (!(ABL & 8) && cc + 1 < nCC) prefetch(cc + 1);
+      // ---- input transform: raw -> V ----
+#pragma unroll
+      for (int i = 0; i < ((ABL & 2) ? 0 : 2); ++i) {
+        f32x4 tc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(raw + tA[i] + j * WN_CKP);
+          const f32x4 y = *reinterpret_cast<const f32x4*>(raw + tB[i] + j * WN_CKP);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) tc[j][k] = fmaf(y[k], tS[i], x[k]);   // exact: s = +-1
+        }
+        f32x4 v0, v1, v2, v3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v0[k] = tc[0][k] - tc[2][k];
+          v1[k] = tc[1][k] + tc[2][k];
+          v2[k] = tc[2][k] - tc[1][k];
+          v3[k] = tc[1][k] - tc[3][k];
+        }
+        *reinterpret_cast<f32x4*>(V + tV[i]) = v0;
+        *reinterpret_cast<f32x4*>(V + tV[i] + WN_VPLANE) = v1;
+        *reinterpret_cast<f32x4*>(V + tV[i] + 2 * WN_VPLANE) = v2;
+        *reinterpret_cast<f32x4*>(V + tV[i] + 3 * WN_VPLANE) = v3;
+      }
+      __syncthreads();   // V of chunk cc complete
+      // ---- 16 GEMMs, this wave's four: 32 MFMAs ----
+      f32x4 av[2][MT];
+      auto load_a = [&](int f, f32x4* d) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          d[mt] = *reinterpret_cast<const f32x4*>(V + (4 * wv + f) * WN_VPLANE + mt * (32 * WN_CK) + aoff);
+      };
+      load_a(0, av[0]);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        if (f + 1 < 4) load_a(f + 1, av[(f + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            if (!(ABL & 4)) acc[f][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[f][j], av[f & 1][mt][j], acc[f][mt], 0, 0, 0);
+            else acc[f][mt][j] += bq[f][j] * av[f & 1][mt][j];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    if (ABL & 1) {   // keep the accumulators alive with one store that never happens
+      float sacc = 0.f;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) sacc += acc[f][mt][j];
+      if (sacc == 12345.678f) a.out.p[tid] = sacc;
+      __syncthreads();
+      continue;
+    }
+    // ---- output transform, first half (this wave's row a = wv: the four b's -> the two output columns q) ----
+    __syncthreads();   // every wave is done with V: the Z exchange may overwrite raw and V
+    {
+      float* zw = smem + (2 * wv) * WN_ZPLANE + r * WN_CP + 4 * h;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 z0, z1;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float m0 = acc[0][mt][4 * g + k], m1 = acc[1][mt][4 * g + k], m2 = acc[2][mt][4 * g + k],
+                        m3 = acc[3][mt][4 * g + k];
+            z0[k] = (m0 + m1) + m2;
+            z1[k] = (m1 - m2) - m3;
+          }
+          *reinterpret_cast<f32x4*>(zw + mt * (32 * WN_CP) + 8 * g) = z0;
+          *reinterpret_cast<f32x4*>(zw + WN_ZPLANE + mt * (32 * WN_CP) + 8 * g) = z1;
+        }
+    }
+    // second half inside the fused epilogue: pixel (py, px) of the wave's 4 x 16 block is output (py & 1, px & 1) of
+    // tile (2 wv + py / 2, px / 2); even rows Z[0] + Z[1] + Z[2], odd rows Z[1] - Z[2] - Z[3]
+#define EPI_PRE_SYNC __syncthreads()
+#define EPI_STAGE
+#define EPI_FETCH(v, py, px)                                                                                         \
+  {                                                                                                                  \
+    const float* zb = smem + ((px)&1) * WN_ZPLANE + ((2 * wvu + ((py) >> 1)) * 8 + ((px) >> 1)) * WN_CP + c4;          \
+    const f32x4 za = *reinterpret_cast<const f32x4*>(zb + (((py)&1) ? 2 : 0) * WN_ZPLANE);                           \
+    const f32x4 zb1 = *reinterpret_cast<const f32x4*>(zb + (((py)&1) ? 4 : 2) * WN_ZPLANE);                          \
+    const f32x4 zc = *reinterpret_cast<const f32x4*>(zb + (((py)&1) ? 6 : 4) * WN_ZPLANE);                           \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) v[k_] = ((py)&1) ? (za[k_] - zb1[k_]) - zc[k_] : (za[k_] + zb1[k_]) + zc[k_]; \
+  }
+#define EPI_HEAD HEAD
+#include "igemm_epilogue.inc"
+#undef EPI_HEAD
+#undef EPI_FETCH
+#undef EPI_STAGE
+#undef EPI_PRE_SYNC
+    if (PERS) __syncthreads();   // the next item's raw tile overwrites the Z planes
+  } while (PERS && (id += gridDim.x) < nPix * nNTall);
+}
+
+template <bool PERS>
+__global__ __launch_bounds__(256, 2) void wino_conv_kernel(const ConvArgs a) {
+  wino_body<PERS, false>(a);
+}
+template <bool PERS>
+__global__ __launch_bounds__(256, 2) void wino_conv_head_kernel(const ConvArgs a) {
+  wino_body<PERS, true>(a);
+}
+#ifdef DEPGAN_WINO_ABLATIONS
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void wino_conv_abl_kernel(const ConvArgs a) {
+  wino_body<true, false, ABL>(a);
+}
+#endif
+
+}  // namespace
+
+bool dg_conv_wino_supported(const ConvPlan& pl, const ConvArgs& a) {
+  if (pl.variant != 9 || pl.bf16 || pl.KS != 3) return false;
+  if (a.Cin != pl.Cin || (a.Cin % WN_CK) || (a.Cout % 32) || a.groups > 1 || a.dbg || ((a.H | a.W) & 1)) return false;
+  if (a.cpt > 0 && ((a.Cin % (a.cpt * WN_CK)) != 0 || a.Cin / (a.cpt * WN_CK) > 4)) return false;
+  return true;
+}
+
+const char* dg_conv_wino_name(const ConvArgs& a) {
+  const long total = (long)cdiv(a.W, 16) * cdiv(a.H, 16) * a.B * (a.Cout / 32);
+  const bool pers = total > 2L * dg_cu_count();
+  if (a.ep.head_out) return pers ? "wino_conv_head_kernel<true>" : "wino_conv_head_kernel<false>";
+  return pers ? "wino_conv_kernel<true>" : "wino_conv_kernel<false>";
+}
+
+int dg_conv_wino(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
+  if (!dg_conv_wino_supported(pl, a_in)) {
+    dg_set_error("dg_conv_wino: shape not covered (3x3, Cin %% 8, Cout %% 32, even H and W, no groups)");
+    return DG_ERR_UNSUPPORTED;
+  }
+  ConvArgs a = a_in;
+  a.lgx = cdiv(a.W, 16) * cdiv(a.H, 16) * a.B;
+  a.lgy = a.Cout / 32;
+  const long total = (long)a.lgx * a.lgy;
+  // two workgroups per CU by LDS (73 KB each) and registers (256); persistent when there are more items than that
+  const long cap = 2L * dg_cu_count();
+  const bool pers = total > cap;
+  const long G = pers ? cap : total;
+  static DgOncePerDevice once;
+  if (once.need()) {
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_head_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_head_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS));
+  }
+#ifdef DEPGAN_WINO_ABLATIONS
+  if (const char* e = getenv("DEPGAN_WINO_ABL")) {
+    const int abl = atoi(e);
+    if (abl && pers && !a.ep.head_out) {
+#define WN_ABL_CASE(N)                                                                                              \
+  case N:                                                                                                           \
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_abl_kernel<N>),                           \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS));                         \
+    hipLaunchKernelGGL((wino_conv_abl_kernel<N>), dim3((unsigned)G), dim3(256), WN_LDS, st, a);                     \
+    break;
+      switch (abl) {
+        WN_ABL_CASE(1) WN_ABL_CASE(2) WN_ABL_CASE(3) WN_ABL_CASE(4) WN_ABL_CASE(8) WN_ABL_CASE(10) WN_ABL_CASE(11)
+        default: dg_set_error("DEPGAN_WINO_ABL=%d not instantiated", abl); return DG_ERR_ARG;
+      }
+      HIPCHECK(hipGetLastError());
+      return DG_OK;
+    }
+  }
+#endif
+  if (a.ep.head_out) {
+    if (a.Cout != 32 || a.ep.pool.p) {
+      dg_set_error("dg_conv_wino: the fused head needs 32 output channels and no fused pool");
+      return DG_ERR_ARG;
+    }
+    if (pers) hipLaunchKernelGGL((wino_conv_head_kernel<true>), dim3((unsigned)G), dim3(256), WN_LDS, st, a);
+    else hipLaunchKernelGGL((wino_conv_head_kernel<false>), dim3((unsigned)G), dim3(256), WN_LDS, st, a);
+  } else {
+    if (pers) hipLaunchKernelGGL((wino_conv_kernel<true>), dim3((unsigned)G), dim3(256), WN_LDS, st, a);
+    else hipLaunchKernelGGL((wino_conv_kernel<false>), dim3((unsigned)G), dim3(256), WN_LDS, st, a);
+  }
+  HIPCHECK(hipGetLastError());
+  return DG_OK;
+}

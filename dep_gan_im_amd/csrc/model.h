@@ -160,6 +160,7 @@ struct depgan_ctx {
   void* rccl_comm = nullptr;       // ncclComm_t of the direct binding (depgan_rccl_init); takes precedence over ar_fn
   long rccl_issued = 0;
   int device = 0;                  // HIP device the context was created on
+  bool winograd = true;           // 3x3 convolutions on the Winograd F(2x2,3x3) kernel where it covers them (DEPGAN_WINOGRAD=0: direct)
   bool head_fused = true;         // gen_segmentation in gen_17's epilogue where the kernel allows (DEPGAN_HEAD_FUSED=0: own launch)
   bool wgrad_bf16 = true;          // bf16_mfma contexts: weight gradients on the bf16 pipe (DEPGAN_WGRAD_BF16=0: fp32)
   float* host_stats = nullptr;     // pinned: un-normalised loss pieces of the updates of one call, fetched asynchronously

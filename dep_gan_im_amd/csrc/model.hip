@@ -107,6 +107,11 @@ static ConvPlan plan_conv(const depgan_ctx* c, int KS, int Cin, int Cout, int N 
   if (c->cfg.f32_split) return dg_plan_conv_split(KS, Cin, Cout, c->cfg.f32_split == 6 ? 3 : 2);
   if (c->cfg.bf16_mfma) return dg_plan_conv_bf16(KS, Cin, Cout);
   const long items = (long)N * cdiv(H, 16) * cdiv(W, 16) * cdiv(Cout, 32);
+  // 3x3 layers the Winograd kernel covers (igemm_wino.hip: 4/9 of the MFMAs of the direct form)
+  if (c->winograd && KS == 3 && H > 0 && W > 0 && !((H | W) & 1)) {
+    const ConvPlan w = dg_plan_conv_wino(Cin, Cout);
+    if (w.variant == 9) return w;
+  }
   return dg_plan_conv_items(KS, Cin, Cout, items);
 }
 
@@ -1320,6 +1325,10 @@ int depgan_create(const depgan_config* cfg, depgan_ctx** out) {
     // tests/test_gpu_model.py::test_fused_head_matches_the_separate_launch)
     const char* hf = getenv("DEPGAN_HEAD_FUSED");
     c->head_fused = !(hf && atoi(hf) == 0);
+    // DEPGAN_WINOGRAD=0: every 3x3 convolution on the direct implicit-GEMM kernel (A/B switch of the parity tests and
+    // of bench.py's `direct_conv` line)
+    const char* wn = getenv("DEPGAN_WINOGRAD");
+    c->winograd = !(wn && atoi(wn) == 0);
   }
   if (c->cfg.nc_out <= 0) c->cfg.nc_out = 1;
   if (c->cfg.nc_out != 1 && c->cfg.nc_out != 4) {
@@ -1814,6 +1823,10 @@ static int op_conv(const float* in, const float* w_hwio, const float* bias, floa
                 : (path == 4 || path == 5) ? dg_plan_conv_split(KS, ci, co, path == 5 ? 3 : 2)
                 : (path == 6) ? dg_plan_conv_items(KS, ci, co, 1L << 30) : dg_plan_conv(KS, ci, co);
   if (path == 7) pl = dg_plan_conv_items(KS, ci, co, 1L << 30);
+  if (path == 8) {
+    pl = (KS == 3) ? dg_plan_conv_wino(ci, co) : pl;
+    if (pl.variant != 9 || !dg_conv_wino_supported(pl, a)) { dg_set_error("op_conv: the Winograd kernel does not cover this shape"); return DG_ERR_UNSUPPORTED; }
+  }
   if ((path == 6 || path == 7) && pl.CK != 8) { dg_set_error("op_conv: the 8-channel-chunk variant does not cover this shape"); return DG_ERR_UNSUPPORTED; }
   if (path >= 3 && path <= 5 && !pl.bf16) { dg_set_error("op_conv: the bf16 MFMA kernel does not cover this shape"); return DG_ERR_UNSUPPORTED; }
   if (path == 1 && pl.variant < 0) { dg_set_error("op_conv: MFMA path not available for this shape"); return DG_ERR_UNSUPPORTED; }

@@ -247,7 +247,8 @@ int depgan_debug_tensor(depgan_ctx* ctx, const char* name, float* host_dst, long
 /* path: 0 auto, 1 fp32 MFMA implicit GEMM, 2 direct, 3 bf16 MFMA implicit GEMM (both operands rounded to bf16, RNE),
  * 4 / 5: fp32 operands split into 2 / 3 bf16 terms, 3 / 6 products on the bf16 pipe (depgan_config.f32_split = 3 / 6),
  * 6: fp32 MFMA with 8-channel chunks, workgroup tiles (large 3x3 launches with more than 64 input channels),
- * 7: the wave-private form of 6 (csrc/igemm_wp.hip: large 3x3 launches with Cin <= 64; bit-identical to 6) */
+ * 7: the wave-private form of 6 (csrc/igemm_wp.hip: large 3x3 launches with Cin <= 64; bit-identical to 6),
+ * 8: Winograd F(2x2,3x3) on the fp32 matrix pipe (csrc/igemm_wino.hip: 3x3, Cin % 8 == 0, Cout % 32 == 0, even H, W) */
 int depgan_op_conv2d(const float* in, const float* w_hwio, const float* bias, float* out, int B, int H, int W,
                      int Cin, int Cout, int KS, int relu, int path, void* hip_stream);
 int depgan_op_conv2d_bwd_data(const float* dy, const float* w_hwio, float* dx, int B, int H, int W, int Cin,

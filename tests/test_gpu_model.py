@@ -88,8 +88,8 @@ def test_fused_head_matches_the_separate_launch(lib, tmp_path):
 
     f1, k1, a1, t1, g1 = run(True)
     f0, k0, a0, t0, g0 = run(False)
-    assert "igemm_conv_head_kernel" in k1 and "head fwd" not in k1, k1
-    assert "igemm_conv_head_kernel" not in k0 and "head fwd" in k0, k0
+    assert "conv_head_kernel" in k1 and "head fwd" not in k1, k1      # igemm_conv_head_kernel / wino_conv_head_kernel
+    assert "conv_head_kernel" not in k0 and "head fwd" in k0, k0
     assert np.array_equal(a1, a0)                       # the convolution itself is the same arithmetic
     assert np.array_equal(f1, t1)                       # with and without the activation store
     d = float(np.abs(f1 - f0).max())

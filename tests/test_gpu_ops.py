@@ -39,6 +39,10 @@ CONV_CASES = [  # B,H,W,Cin,Cout,k,path
     # channel tiles, one to eight K chunks, persistent (>= 8 super-tiles per XCD form) and one-item workgroups
     (2, 32, 32, 32, 32, 3, 7), (2, 48, 40, 32, 64, 3, 7), (2, 21, 19, 64, 160, 3, 7), (2, 30, 18, 8, 32, 3, 7),
     (8, 64, 128, 64, 64, 3, 7), (3, 16, 64, 16, 96, 3, 7),
+    # path 8: Winograd F(2x2,3x3) on the fp32 matrix pipe (igemm_wino.hip; even H and W, Cin % 8, Cout % 32): ragged
+    # 16 x 16 tiles, one to 28 K chunks, several channel tiles, one-item and persistent workgroups
+    (2, 32, 32, 32, 32, 3, 8), (2, 48, 40, 32, 64, 3, 8), (1, 32, 32, 224, 96, 3, 8), (2, 22, 18, 64, 160, 3, 8),
+    (1, 16, 16, 256, 256, 3, 8), (2, 30, 18, 8, 32, 3, 8), (32, 64, 64, 32, 64, 3, 8), (5, 100, 72, 40, 32, 3, 8),
     (2, 32, 32, 1, 32, 3, 2), (2, 32, 32, 2, 32, 3, 2), (2, 30, 18, 1, 16, 5, 2), (2, 32, 32, 16, 1, 5, 2),
     # single output channel (dD/dx): the 4-pixels-per-thread kernel, ragged tiles, channel tails, both kernel sizes
     (2, 45, 70, 16, 1, 5, 2), (2, 33, 31, 8, 1, 3, 2), (1, 40, 40, 6, 1, 5, 2), (1, 20, 36, 12, 1, 3, 2),
@@ -65,7 +69,7 @@ def test_conv_forward_and_backward_data(lib, case):
     dx = torch.full((B, H, W, ci), float("nan"), device=dev)
     # path 6 (8-channel chunks) exists for 32-channel output tiles only: the backward of a layer with fewer input
     # channels than that runs the 16-channel-chunk kernel
-    bpath = 1 if (path in (6, 7) and ci % 32) else path
+    bpath = 1 if (path in (6, 7, 8) and ci % 32) else path
     if bpath == 7 and co > 64:
         bpath = 6            # the backward of this layer has more than 64 input channels: workgroup tiles
     _lib.check(lib.depgan_op_conv2d_bwd_data(P(dyd), P(wd), P(dx), B, H, W, ci, co, k, bpath, None))
@@ -365,3 +369,27 @@ def test_persistent_conv_grid_matches_one_item_per_workgroup(lib, case, monkeypa
     np.testing.assert_array_equal(outs[0], outs[2])
     ref = _ref_conv(x[:2].cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), True)
     assert rel(outs[1][:2], ref) < TOL
+
+
+@pytest.mark.parametrize("case", [(4, 64, 64, 32, 32), (4, 64, 64, 64, 64), (2, 32, 32, 128, 128), (2, 16, 16, 256, 256)])
+def test_winograd_conv_rounding_error_next_to_the_direct_kernel(lib, case):
+    """igemm_wino.hip computes the same fp32 contraction with another summation tree (F(2x2,3x3): additions before and
+    after 4/9 of the multiplications).  On post-ReLU-like operands of the network's scale: its error against an fp64
+    convolution stays within 4 x the direct MFMA kernel's and below 2e-6 of the output's range."""
+    from dep_gan_im_amd import _lib
+    B, H, W, ci, co = case
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(ci + co)
+    x = np.maximum(rng.standard_normal((B, H, W, ci)), 0).astype(np.float32)
+    w = (rng.standard_normal((3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    ref = _ref_conv(x, w, None, False)
+    xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    errs = {}
+    for path in (1, 8):
+        out = torch.full((B, H, W, co), float("nan"), device=dev)
+        _lib.check(lib.depgan_op_conv2d(P(xd), P(wd), None, P(out), B, H, W, ci, co, 3, 0, path, None))
+        torch.cuda.synchronize()
+        e = np.abs(out.cpu().numpy().astype(np.float64) - ref)
+        errs[path] = (float(e.max() / np.abs(ref).max()), float(np.sqrt((e ** 2).mean()) / np.abs(ref).max()))
+    print("conv %s: direct max %.2e rms %.2e | winograd max %.2e rms %.2e" % (case, *errs[1], *errs[8]))
+    assert errs[8][0] < 2e-6 and errs[8][1] < 4.0 * errs[1][1]
