@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_abl_kernel(const ConvArgs a)
 }
 #endif
 
+
 }  // namespace
 
 bool dg_conv_wino_supported(const ConvPlan& pl, const ConvArgs& a) {

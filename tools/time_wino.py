@@ -37,9 +37,9 @@ def run():
 
 def parse(d):
     f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[-1]
-    rows = [r for r in csv.DictReader(open(f)) if "igemm_conv_kernel" in r["Kernel_Name"] or "wino_conv" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "igemm_conv_kernel" in r["Kernel_Name"] or "wino_" in r["Kernel_Name"]]
     if os.environ.get("WINO_ONLY"):   # ablation runs: the Winograd launches only
-        rows = [r for r in rows if "wino_conv" in r["Kernel_Name"]]
+        rows = [r for r in rows if "wino_" in r["Kernel_Name"]]
         for i, (B, H, W, ci, co) in enumerate(SHAPES):
             rr = rows[i * REPS:(i + 1) * REPS]
             us = min((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rr[1:])
