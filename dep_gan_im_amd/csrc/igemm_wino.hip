@@ -32,33 +32,53 @@
 namespace {
 
 constexpr int WN_CK = 8, WN_CKP = 12;           // channels per chunk; floats per raw halo pixel (48 B rows)
-constexpr int WN_TW = 18, WN_PIXT = WN_TW * WN_TW;
-constexpr int WN_RAW = WN_PIXT * WN_CKP;        // 3888 floats
-constexpr int WN_VPLANE = 64 * WN_CK + 4;       // one frequency: 64 tiles x 8 channels, +16 B so that the four a's of a
-                                                // transform write (planes 4 apart) fall into different bank groups
-constexpr int WN_V = 16 * WN_VPLANE;            // 8256 floats
+constexpr int WN_TW = 18;                       // halo columns of a 16-pixel-wide tile
 constexpr int WN_CP = 36;                       // floats per tile row of the Z exchange (32 channels + 4)
-constexpr int WN_ZPLANE = 64 * WN_CP + 32;      // one (a, q): +128 B so that q = 0 / 1 of a pixel pair differ in bank group
-constexpr int WN_Z = 8 * WN_ZPLANE;             // 18688 floats
 constexpr int WN_XV = WN_CK / 4;
-constexpr int WN_XTOT = WN_PIXT * WN_XV;        // 648 16-byte pieces of a raw chunk
-constexpr int WN_XPIECES = (WN_XTOT + 255) / 256;
-constexpr size_t WN_LDS = sizeof(float) * (size_t)((WN_RAW + WN_V) > WN_Z ? (WN_RAW + WN_V) : WN_Z);
+
+// MT = MFMA row tiles (32 Winograd tiles = 8 x 16 output pixels each) per wave: the workgroup's pixel tile is 8 MT rows
+// x 16 columns.  MT = 2: 128 accumulator registers per wave, two workgroups per CU.  MT = 1: 64, three per CU -- more
+// waves per SIMD to keep the matrix pipe busy (one wave reaches 0.60 of it, two 0.72, four 0.84:
+// profiles/r03_conv_experiments.md) at twice the weight-fragment traffic per MFMA and a larger halo share.
+template <int MT>
+struct WnCfg {
+  static constexpr int TH = 8 * MT;                     // output rows per workgroup
+  static constexpr int NTILE = 32 * MT;                 // Winograd tiles per workgroup
+  static constexpr int PIXT = (TH + 2) * WN_TW;         // raw halo pixels
+  static constexpr int RAW = PIXT * WN_CKP;             // floats
+  // one frequency: tiles x 8 channels, unpadded; its 16-byte slots are XOR-swizzled (vslot below): the LDS serves a
+  // b128 access eight lanes at a time out of 128 bytes of banks, so eight consecutive lanes must hit eight different
+  // slots modulo 8 -- lanes r and r + 4 of a fragment read (32-byte rows) and the four a's of a transform write
+  // (whole planes apart) would not (counters: half of the LDS cycles of the unswizzled form were bank conflicts)
+  static constexpr int VPLANE = NTILE * WN_CK;
+  static constexpr int V = 16 * VPLANE;
+  static constexpr int ZPLANE = NTILE * WN_CP + 32;     // one (a, q): +128 B so that q = 0 / 1 of a pixel pair differ in bank group
+  static constexpr int Z = 8 * ZPLANE;
+  static constexpr int XTOT = PIXT * WN_XV;             // 16-byte pieces of a raw chunk
+  static constexpr int XPIECES = (XTOT + 255) / 256;
+  static constexpr size_t LDS = sizeof(float) * (size_t)((RAW + V) > Z ? (RAW + V) : Z);
+  static constexpr int WGS_PER_CU = (MT == 2) ? 2 : 3;
+};
 
 // ABL: ablation bits for tools/time_wino.py (0 = the product kernel; the others are compiled with
 // -DDEPGAN_WINO_ABLATIONS only): 1 no epilogue, 2 no input transform, 4 no MFMAs, 8 no raw staging
-template <bool PERS, bool HEAD, int ABL = 0>
+// float offset inside a V plane of 16-byte slot (tile T, channel half cg) of the frequencies of transform row a
+static __device__ __forceinline__ int vslot(int T, int cg, int a) { return ((2 * T + cg) ^ ((T >> 2) & 1) ^ (a << 1)) << 2; }
+
+template <int MT, bool PERS, bool HEAD, int ABL = 0>
 static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
-  constexpr int MF = 32, NT = 32, MT = 2;
+  typedef WnCfg<MT> C;
+  constexpr int MF = 32, NT = 32;
+  constexpr int WN_RAW = C::RAW, WN_VPLANE = C::VPLANE, WN_ZPLANE = C::ZPLANE, WN_XTOT = C::XTOT, WN_XPIECES = C::XPIECES;
   typedef f32x16 acc_t;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* raw = smem;            // [324][12]
+  float* raw = smem;            // [(8 MT + 2) x 18][12]
   float* V = smem + WN_RAW;     // [16][WN_VPLANE]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + 15) >> 4;
+  const int tilesX = (a.W + 15) >> 4, tilesY = (a.H + C::TH - 1) / C::TH;
   const unsigned nNTall = (unsigned)a.lgy, nPix = (unsigned)a.lgx;
   const int nCC = a.Cin / WN_CK;
 
@@ -79,22 +99,24 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
   // transform task i: q = tid + 256 i -> channel group q & 1, transform row a = (q >> 1) & 3, tile q >> 3.
   // Row a of B^T d needs two of the tile's four halo rows:  a = 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3
   // = x + s y with (x, y) = rows (0,2) (1,2) (2,1) (1,3) and s = +1 for a = 1, else -1.
-  int tA[2], tB[2], tV[2];
-  float tS[2];
+  int tA[MT], tB[MT], tV[MT];
+  float tS[MT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MT; ++i) {
     const int q = tid + 256 * i;
     const int cg = q & 1, aa = (q >> 1) & 3, T = q >> 3;
     const int tyi = T >> 3, txi = T & 7;
     const int rA = (aa == 0) ? 0 : (aa == 2 ? 2 : 1), rB = (aa == 3) ? 3 : (aa == 2 ? 1 : 2);
     tA[i] = ((2 * tyi + rA) * WN_TW + 2 * txi) * WN_CKP + 4 * cg;
     tB[i] = ((2 * tyi + rB) * WN_TW + 2 * txi) * WN_CKP + 4 * cg;
-    tV[i] = (4 * aa) * WN_VPLANE + T * WN_CK + 4 * cg;
+    tV[i] = (4 * aa) * WN_VPLANE + vslot(T, cg, aa);
     tS[i] = (aa == 1) ? 1.f : -1.f;
   }
   const unsigned rawb0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)raw;
   // fragments: A = V[f][32 mt + r][4h ..], B = panel[f][r][4h ..]
-  const int aoff = r * WN_CK + 4 * h;
+  int aoff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) aoff[mt] = vslot(32 * mt + r, h, wv);
   const int boff = (4 * wv * 32 + r) * WN_CK + 4 * h;
 
   unsigned id = blockIdx.x;
@@ -110,12 +132,12 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     }
     const int tx0 = (t % tilesX) * 16;
     t /= tilesX;
-    const int ty0 = (t % tilesY) * 16;
+    const int ty0 = (t % tilesY) * C::TH;
     const int b = t / tilesY;
     const long out_goff = 0;
     const int n0 = ntile * NT;
     const float* inb = a.in.p + (long)b * a.in.sB;
-    const bool interior = ty0 >= 1 && ty0 + 17 <= a.H && tx0 >= 1 && tx0 + 17 <= a.W;
+    const bool interior = ty0 >= 1 && ty0 + C::TH + 1 <= a.H && tx0 >= 1 && tx0 + 17 <= a.W;
     const char* halo0 = reinterpret_cast<const char*>(inb + ((long)(ty0 - 1) * a.in.sY + (long)(tx0 - 1) * a.in.sX));
     auto coff = [&](int cc) -> long {
       if (a.cpt > 0) {
@@ -173,7 +195,7 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
       if (!(ABL & 8) && cc + 1 < nCC) prefetch(cc + 1);
       // ---- input transform: raw -> V ----
 #pragma unroll
-      for (int i = 0; i < ((ABL & 2) ? 0 : 2); ++i) {
+      for (int i = 0; i < ((ABL & 2) ? 0 : MT); ++i) {
         f32x4 tc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -201,7 +223,7 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
       auto load_a = [&](int f, f32x4* d) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          d[mt] = *reinterpret_cast<const f32x4*>(V + (4 * wv + f) * WN_VPLANE + mt * (32 * WN_CK) + aoff);
+          d[mt] = *reinterpret_cast<const f32x4*>(V + (4 * wv + f) * WN_VPLANE + aoff[mt]);
       };
       load_a(0, av[0]);
 #pragma unroll
@@ -254,9 +276,13 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     // tile (2 wv + py / 2, px / 2); even rows Z[0] + Z[1] + Z[2], odd rows Z[1] - Z[2] - Z[3]
 #define EPI_PRE_SYNC __syncthreads()
 #define EPI_STAGE
+#define EPI_NPASS (4 * MT)
+#define EPI_OYW (ty0 + 2 * MT * __builtin_amdgcn_readfirstlane(wv))
+#define EPI_FULL ((ty0 + C::TH <= a.H) && (tx0 + 16 <= a.W))
 #define EPI_FETCH(v, py, px)                                                                                         \
   {                                                                                                                  \
-    const float* zb = smem + ((px)&1) * WN_ZPLANE + ((2 * wvu + ((py) >> 1)) * 8 + ((px) >> 1)) * WN_CP + c4;          \
+    const float* zb = smem + ((px)&1) * WN_ZPLANE +                                                                  \
+                      ((MT * __builtin_amdgcn_readfirstlane(wv) + ((py) >> 1)) * 8 + ((px) >> 1)) * WN_CP + c4;       \
     const f32x4 za = *reinterpret_cast<const f32x4*>(zb + (((py)&1) ? 2 : 0) * WN_ZPLANE);                           \
     const f32x4 zb1 = *reinterpret_cast<const f32x4*>(zb + (((py)&1) ? 4 : 2) * WN_ZPLANE);                          \
     const f32x4 zc = *reinterpret_cast<const f32x4*>(zb + (((py)&1) ? 6 : 4) * WN_ZPLANE);                           \
@@ -266,27 +292,29 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
 #include "igemm_epilogue.inc"
 #undef EPI_HEAD
 #undef EPI_FETCH
+#undef EPI_FULL
+#undef EPI_OYW
+#undef EPI_NPASS
 #undef EPI_STAGE
 #undef EPI_PRE_SYNC
     if (PERS) __syncthreads();   // the next item's raw tile overwrites the Z planes
   } while (PERS && (id += gridDim.x) < nPix * nNTall);
 }
 
-template <bool PERS>
-__global__ __launch_bounds__(256, 2) void wino_conv_kernel(const ConvArgs a) {
-  wino_body<PERS, false>(a);
+template <int MT, bool PERS>
+__global__ __launch_bounds__(256, WnCfg<MT>::WGS_PER_CU) void wino_conv_kernel(const ConvArgs a) {
+  wino_body<MT, PERS, false>(a);
 }
 template <bool PERS>
 __global__ __launch_bounds__(256, 2) void wino_conv_head_kernel(const ConvArgs a) {
-  wino_body<PERS, true>(a);
+  wino_body<2, PERS, true>(a);
 }
 #ifdef DEPGAN_WINO_ABLATIONS
-template <int ABL>
-__global__ __launch_bounds__(256, 2) void wino_conv_abl_kernel(const ConvArgs a) {
-  wino_body<true, false, ABL>(a);
+template <int MT, int ABL>
+__global__ __launch_bounds__(256, WnCfg<MT>::WGS_PER_CU) void wino_conv_abl_kernel(const ConvArgs a) {
+  wino_body<MT, true, false, ABL>(a);
 }
 #endif
-
 
 }  // namespace
 
@@ -297,36 +325,61 @@ bool dg_conv_wino_supported(const ConvPlan& pl, const ConvArgs& a) {
   return true;
 }
 
-const char* dg_conv_wino_name(const ConvArgs& a) {
-  const long total = (long)cdiv(a.W, 16) * cdiv(a.H, 16) * a.B * (a.Cout / 32);
-  const bool pers = total > 2L * dg_cu_count();
-  if (a.ep.head_out) return pers ? "wino_conv_head_kernel<true>" : "wino_conv_head_kernel<false>";
-  return pers ? "wino_conv_kernel<true>" : "wino_conv_kernel<false>";
+// MT of a launch: DEPGAN_WINO_MT=1|2 forces one form for A/B runs; the fused head exists for MT = 2 only
+static int wino_mt(const ConvArgs& a) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("DEPGAN_WINO_MT");
+    forced = e ? atoi(e) : 0;
+  }
+  if (a.ep.head_out) return 2;
+  if (forced == 1 || forced == 2) return forced;
+  // 8-row tiles where 16-row tiles would leave CUs without a workgroup (measured: 16x16 images at batch 32, 256 items
+  // of 16 rows: 61.8 -> 57.9 us; equal within 1 % everywhere else, profiles/r03_conv_experiments.md)
+  const long items16 = (long)cdiv(a.W, 16) * cdiv(a.H, 16) * a.B * (a.Cout / 32);
+  return items16 <= 2L * dg_cu_count() ? 1 : 2;
 }
 
-int dg_conv_wino(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
-  if (!dg_conv_wino_supported(pl, a_in)) {
-    dg_set_error("dg_conv_wino: shape not covered (3x3, Cin %% 8, Cout %% 32, even H and W, no groups)");
-    return DG_ERR_UNSUPPORTED;
-  }
-  ConvArgs a = a_in;
-  a.lgx = cdiv(a.W, 16) * cdiv(a.H, 16) * a.B;
+template <int MT>
+static void wino_geometry(ConvArgs& a, long* total, long* G, bool* pers) {
+  a.lgx = cdiv(a.W, 16) * cdiv(a.H, WnCfg<MT>::TH) * a.B;
   a.lgy = a.Cout / 32;
-  const long total = (long)a.lgx * a.lgy;
-  // two workgroups per CU by LDS (73 KB each) and registers (256); persistent when there are more items than that
-  const long cap = 2L * dg_cu_count();
-  const bool pers = total > cap;
-  const long G = pers ? cap : total;
+  *total = (long)a.lgx * a.lgy;
+  // resident workgroups per CU by LDS and registers; persistent when there are more items than that
+  const long cap = (long)WnCfg<MT>::WGS_PER_CU * dg_cu_count();
+  *pers = *total > cap;
+  *G = *pers ? cap : *total;
+}
+
+const char* dg_conv_wino_name(const ConvArgs& a_in) {
+  ConvArgs a = a_in;
+  long total, G;
+  bool pers;
+  const int mt = wino_mt(a);
+  if (mt == 2) wino_geometry<2>(a, &total, &G, &pers); else wino_geometry<1>(a, &total, &G, &pers);
+  if (a.ep.head_out) return pers ? "wino_conv_head_kernel<true>" : "wino_conv_head_kernel<false>";
+  if (mt == 2) return pers ? "wino_conv_kernel<2,true>" : "wino_conv_kernel<2,false>";
+  return pers ? "wino_conv_kernel<1,true>" : "wino_conv_kernel<1,false>";
+}
+
+template <int MT>
+static int wino_launch(ConvArgs a, hipStream_t st) {
+  long total, G;
+  bool pers;
+  wino_geometry<MT>(a, &total, &G, &pers);
+  constexpr size_t LDS = WnCfg<MT>::LDS;
   static DgOncePerDevice once;
   if (once.need()) {
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_head_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_head_kernel<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    if (MT == 2) {
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_head_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_head_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    }
   }
 #ifdef DEPGAN_WINO_ABLATIONS
   if (const char* e = getenv("DEPGAN_WINO_ABL")) {
@@ -334,9 +387,9 @@ int dg_conv_wino(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
     if (abl && pers && !a.ep.head_out) {
 #define WN_ABL_CASE(N)                                                                                              \
   case N:                                                                                                           \
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_abl_kernel<N>),                           \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS));                         \
-    hipLaunchKernelGGL((wino_conv_abl_kernel<N>), dim3((unsigned)G), dim3(256), WN_LDS, st, a);                     \
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_abl_kernel<MT, N>),                       \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));                            \
+    hipLaunchKernelGGL((wino_conv_abl_kernel<MT, N>), dim3((unsigned)G), dim3(256), LDS, st, a);                    \
     break;
       switch (abl) {
         WN_ABL_CASE(1) WN_ABL_CASE(2) WN_ABL_CASE(3) WN_ABL_CASE(4) WN_ABL_CASE(8) WN_ABL_CASE(10) WN_ABL_CASE(11)
@@ -348,16 +401,24 @@ int dg_conv_wino(const ConvPlan& pl, const ConvArgs& a_in, hipStream_t st) {
   }
 #endif
   if (a.ep.head_out) {
-    if (a.Cout != 32 || a.ep.pool.p) {
+    if (MT != 2 || a.Cout != 32 || a.ep.pool.p) {
       dg_set_error("dg_conv_wino: the fused head needs 32 output channels and no fused pool");
       return DG_ERR_ARG;
     }
-    if (pers) hipLaunchKernelGGL((wino_conv_head_kernel<true>), dim3((unsigned)G), dim3(256), WN_LDS, st, a);
-    else hipLaunchKernelGGL((wino_conv_head_kernel<false>), dim3((unsigned)G), dim3(256), WN_LDS, st, a);
+    if (pers) hipLaunchKernelGGL((wino_conv_head_kernel<true>), dim3((unsigned)G), dim3(256), LDS, st, a);
+    else hipLaunchKernelGGL((wino_conv_head_kernel<false>), dim3((unsigned)G), dim3(256), LDS, st, a);
   } else {
-    if (pers) hipLaunchKernelGGL((wino_conv_kernel<true>), dim3((unsigned)G), dim3(256), WN_LDS, st, a);
-    else hipLaunchKernelGGL((wino_conv_kernel<false>), dim3((unsigned)G), dim3(256), WN_LDS, st, a);
+    if (pers) hipLaunchKernelGGL((wino_conv_kernel<MT, true>), dim3((unsigned)G), dim3(256), LDS, st, a);
+    else hipLaunchKernelGGL((wino_conv_kernel<MT, false>), dim3((unsigned)G), dim3(256), LDS, st, a);
   }
   HIPCHECK(hipGetLastError());
   return DG_OK;
+}
+
+int dg_conv_wino(const ConvPlan& pl, const ConvArgs& a, hipStream_t st) {
+  if (!dg_conv_wino_supported(pl, a)) {
+    dg_set_error("dg_conv_wino: shape not covered (3x3, Cin %% 8, Cout %% 32, even H and W, no groups)");
+    return DG_ERR_UNSUPPORTED;
+  }
+  return wino_mt(a) == 2 ? wino_launch<2>(a, st) : wino_launch<1>(a, st);
 }
