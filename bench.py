@@ -18,6 +18,7 @@ Extra objects on the same line at N = 1 (each builds an engine of its own after 
   config5:   BASELINE configs[4], the DEP-UResNet supervised step
   f32_split: the headline workload with the opt-in split-product convolutions (fp32 operands as exact sums of bf16
              terms, six / three cross products on the bf16 pipe)
+  direct_conv: the headline workload with DEPGAN_WINOGRAD=0 (3x3 layers on the direct implicit-GEMM kernel)
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline:     MFMA implicit-GEMM convolution class (dominant kernels) --
@@ -123,6 +124,12 @@ def pmc_traffic(batch, launches_per_step):
         best, n, n // launches_per_step, launches_per_step)
 
 
+def issued_share(kernel_name):
+    """MFMA flops a kernel issues per algorithmic flop of its convolution: 4/9 for the Winograd F(2x2,3x3) kernels
+    (csrc/igemm_wino.hip: 16 multiplications per 2x2 outputs and input channel instead of 36), 1 for the direct ones."""
+    return 4.0 / 9.0 if kernel_name.startswith("wino_") else 1.0
+
+
 def dominant_kernel(eng, steps):
     """The convolution class split by kernel instantiation (the names rocprofv3 --kernel-trace --stats prints), from the
     HIP-event records of the profiled steps: the instantiation with the largest share of the step, and inside it the
@@ -139,26 +146,38 @@ def dominant_kernel(eng, steps):
     if not rows:
         return None
     by_k, by_s = {}, {}
+    tot_ms = tot_gf = tot_issued = 0.0
     for r in rows:
         for d, key in ((by_k, r["kernel"]), (by_s, (r["kernel"], r["label"]))):
             a = d.setdefault(key, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += float(r["ms"])
             a[2] += float(r["gflop"])
+        tot_ms += float(r["ms"])
+        tot_gf += float(r["gflop"])
+        tot_issued += float(r["gflop"]) * issued_share(r["kernel"])
     kname, (kn, kms, kgf) = max(by_k.items(), key=lambda kv: kv[1][1])
     (_, sname), (sn, sms, sgf) = max(((k, v) for k, v in by_s.items() if k[0] == kname), key=lambda kv: kv[1][1])
 
-    def line(n, ms, gf):
+    def line(n, ms, gf, share=1.0):
         tf = gf / ms if ms > 0 else 0.0            # GFLOP / ms = TFLOP/s
-        return {"launches_per_step": n // steps, "avg_launch_us": round(ms / n * 1e3, 2),
-                "gflop_per_launch": round(gf / n, 3), "ms_per_step": round(ms / steps, 3),
-                "achieved": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA, 4)}
+        d = {"launches_per_step": n // steps, "avg_launch_us": round(ms / n * 1e3, 2),
+             "gflop_per_launch": round(gf / n, 3), "ms_per_step": round(ms / steps, 3),
+             "achieved": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA, 4)}
+        if share != 1.0:
+            # Winograd F(2x2,3x3): `achieved` prices the ALGORITHMIC flops of the convolution (2 x 9 x Cin x
+            # Cout per pixel); the matrix pipe is issued 4/9 of them -- its own utilisation is this line
+            d["mfma_issued_frac"] = round(tf * share / PEAK_F32_MFMA, 4)
+        return d
     out = {"kernel": kname, "unit": "TFLOP/s", "peak": PEAK_F32_MFMA}
-    out.update(line(kn, kms, kgf))
+    out.update(line(kn, kms, kgf, issued_share(kname)))
+    out["class_mfma_issued_frac"] = round(tot_issued / tot_ms / PEAK_F32_MFMA, 4) if tot_ms > 0 else None
+    out["class_by_kernel"] = {k: {"ms_per_step": round(v[1] / steps, 3), "frac": round(v[2] / v[1] / PEAK_F32_MFMA, 4)}
+                              for k, v in sorted(by_k.items(), key=lambda kv: -kv[1][1]) if v[1] > 0}
     out["recompute"] = ("gflop_per_launch / avg_launch_us / %.1f; the average duration of this kernel name in "
                         "profiles/*_kernel_stats.csv (rocprofv3 --kernel-trace --stats over the same command with "
                         "DEPGAN_BENCH_STEP_ONLY=1) must agree with avg_launch_us" % PEAK_F32_MFMA)
-    out["largest_shape"] = dict(shape=sname, **line(sn, sms, sgf))
+    out["largest_shape"] = dict(shape=sname, **line(sn, sms, sgf, issued_share(kname)))
     return out
 
 
@@ -218,6 +237,52 @@ def bench_config4(dg, torch, dev, B, steps=5):
                          "note": "algorithmic bytes (operands once, results once) / HIP-event time; the contraction "
                                  "itself runs at %.1f TFLOP/s = %.3f of the 2500 TFLOP/s dense bf16 peak, i.e. this "
                                  "class sits on the HBM side of the roofline" % (tf, tf / 2500.0)}}
+
+
+def bench_direct(dg, torch, dev, B, x, y2, z, ep, steps=5):
+    """The headline workload with every 3x3 convolution on the direct implicit-GEMM kernel (DEPGAN_WINOGRAD=0, read when
+    the context is created): what the Winograd kernel is measured against, same process, same inputs."""
+    os.environ["DEPGAN_WINOGRAD"] = "0"
+    try:
+        nets = [dg.Gen_UNet2D((256, 256, 1), (32, 1), 32, 1, seed=1), dg.Dis_C2D_FCN1((256, 256, 1), seed=2),
+                dg.Dis_C2D_FCN1((256, 256, 1), seed=3)]
+        tr = dg.build_trainers(*nets, batchSize=B, IM_TRSH=0.178, device=dev)
+    finally:
+        del os.environ["DEPGAN_WINOGRAD"]
+
+    def step():
+        tr.netD_y2_train([y2, x, z, ep])
+        tr.netD_dem_train([y2, x, z, ep])
+        tr.netG_train([x, y2, z])
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    eng = tr.engine
+    eng.profile(True)
+    eng.profile_reset()
+    step()
+    c_ms, _, c_fl = eng.profile_read(0)
+    eng.profile(False)
+    eng.profile_reset()
+    eng.g_forward(x, z)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        eng.g_forward(x, z)
+    torch.cuda.synchronize()
+    gf = (time.perf_counter() - t1) / 5 * 1e3
+    eng.close()
+    tf = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
+    return {"note": "DEPGAN_WINOGRAD=0: all convolutions on igemm_conv_kernel (direct implicit GEMM)",
+            "ms_per_step": round(ms, 3), "slices_per_s": round(B / (ms * 1e-3), 1),
+            "conv_class": {"ms_per_step": round(c_ms, 3), "achieved": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA, 4)},
+            "g_forward": {"ms": round(gf, 3), "frac": round(23.513e9 * B / (gf * 1e-3) / 1e12 / PEAK_F32_MFMA, 4)}}
 
 
 def bench_split(dg, torch, dev, B, x, y2, z, ep, steps=5):
@@ -595,6 +660,9 @@ def main():
     f32_split = None
     if world == 1 and rank == 0 and not os.environ.get("DEPGAN_BENCH_SKIP_SPLIT") and not tr.engine.f32_split:
         f32_split = bench_split(dg, torch, dev, B, x, y2, z, ep)
+    direct_conv = None
+    if world == 1 and rank == 0 and not os.environ.get("DEPGAN_BENCH_SKIP_DIRECT") and os.environ.get("DEPGAN_WINOGRAD") != "0":
+        direct_conv = bench_direct(dg, torch, dev, B, x, y2, z, ep)
     # ---- extra: BASELINE configs[4], the DEP-UResNet supervised step (learning phase 1, softmax / CE head) ----
     config5 = None
     if world == 1 and rank == 0 and not os.environ.get("DEPGAN_BENCH_SKIP_CONFIG5"):
@@ -605,8 +673,11 @@ def main():
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; "
                                 "%s)" % traffic_src,
                 "algorithmic_bytes_per_launch": round(conv_bytes / max(conv_n, 1)),
-                "kernel": "igemm_conv_kernel (all shapes: fwd / bwd-data / GP u-forward) + the 3 deconv_fwd_kernel "
-                          "launches of the generator forward (the convolution class; `traffic` is the igemm kernels')",
+                "kernel": "the convolution class: wino_conv_kernel (3x3 layers of 32-channel tiles: Winograd F(2x2,3x3) on "
+                          "the fp32 matrix pipe, 4/9 of the direct form's MFMAs) + igemm_conv_kernel (5x5, 1x1, 16-channel "
+                          "tiles, GP u-forward) + the 3 deconv_fwd_kernel launches of the generator forward; `achieved` "
+                          "prices ALGORITHMIC flops (SURVEY 8d), dominant_kernel.class_mfma_issued_frac the flops the "
+                          "matrix pipe was actually issued; direct_conv = the same step with DEPGAN_WINOGRAD=0",
                 "avg_launch_us": round(conv_ms / max(conv_n, 1) * 1e3, 2), "launches_per_step": conv_n // 2,
                 "dominant_kernel": dominant,
                 "wgrad": {"achieved": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2) if wg_ms > 0 else 0.0,
@@ -652,6 +723,8 @@ def main():
             line["config5"] = config5
         if f32_split is not None:
             line["f32_split"] = f32_split
+        if direct_conv is not None:
+            line["direct_conv"] = direct_conv
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

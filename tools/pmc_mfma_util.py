@@ -56,7 +56,7 @@ def main():
         busy = sum(v[1] for _, v in sel); gui = sum(v[2] for _, v in sel); ns = sum(v[3] for _, v in sel)
         return {"launches": sum(v[0] for _, v in sel), "mfma_util": busy / (1024.0 * gui / 8.0) if gui else None,
                 "clock_ghz": gui / 8.0 / ns if ns else None}
-    summary = {"igemm_conv_kernel_class": fold("igemm_conv_kernel", "deconv_fwd_kernel"),     # bench.py's class 0
+    summary = {"igemm_conv_kernel_class": fold("igemm_conv_kernel", "igemm_conv_head_kernel", "wino_conv_kernel", "wino_conv_head_kernel", "deconv_fwd_kernel"),     # bench.py's class 0
                "wgrad_dma_kernel_class": fold("wgrad_dma_kernel", "deconv_wgrad_kernel"),    # ... and class 1
                "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); clock = GUI_ACTIVE / 8 / duration",
                "kernels": rows}

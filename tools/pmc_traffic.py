@@ -15,6 +15,9 @@ import os
 import sys
 from collections import defaultdict
 
+# kernels of bench.py's convolution class (class 0 of the library's profile records)
+CLASS0 = ("igemm_conv_kernel", "igemm_conv_head_kernel", "wino_conv_kernel", "wino_conv_head_kernel", "deconv_fwd_kernel")
+
 
 def load(d, counter):
     acc = defaultdict(lambda: [0, 0.0])
@@ -49,7 +52,7 @@ def main():
         wr = 1024.0 * sw / nw if nw else None
         rows[name] = {"launches": max(nf, nw), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                       "hbm_bytes_per_launch": (rd or 0.0) + (wr or 0.0)}
-    cls = [v for k, v in rows.items() if "igemm_conv_kernel" in k or "deconv_fwd_kernel" in k]   # bench.py's class 0
+    cls = [v for k, v in rows.items() if any(n in k for n in CLASS0)]   # bench.py's class 0
     n = sum(v["launches"] for v in cls)
     summary = {"igemm_conv_kernel_class": {
         "launches": n,

@@ -25,6 +25,11 @@ if "f32_split" in d:
     for k, v in d["f32_split"].items():
         if isinstance(v, dict):
             print("f32_split", k, v["ms_per_step"], "ms", v["slices_per_s"], v["roofline"]["frac"])
+if "direct_conv" in d:
+    c = d["direct_conv"]
+    print("direct_conv", c["ms_per_step"], "ms", c["slices_per_s"], "slices/s conv", c["conv_class"], "g_forward", c["g_forward"])
+if r and r.get("dominant_kernel"):
+    print("class issued-MFMA frac", r["dominant_kernel"].get("class_mfma_issued_frac"), "by kernel", r["dominant_kernel"].get("class_by_kernel"))
 if "collectives" in d:
     print("collectives", d["collectives"], d.get("scaling_efficiency"))
 if "cpu_baseline" in d:
