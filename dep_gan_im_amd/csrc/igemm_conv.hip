@@ -605,31 +605,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
-// Element f = 4a + b of the Winograd weight transform U = G g G^T of one (input channel, output channel) pair, G =
-// [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: the (up to nine) terms in double, rounded to fp32 once.  g is what the direct
-// kernel multiplies with: the fp32 source element (x kscale, rounded to fp32 as the plain panel stores it).
-static __device__ __forceinline__ float wino_weight(const float* __restrict__ e0, size_t tap_stride, int f, int flip,
-                                                     float ks, bool has_ks) {
-  const int a = f >> 2, b = f & 3;
-  double s = 0.0;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const double ga = (a == 0) ? (i == 0 ? 1.0 : 0.0) : (a == 3) ? (i == 2 ? 1.0 : 0.0) : ((a == 2 && i == 1) ? -0.5 : 0.5);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const double gb = (b == 0) ? (j == 0 ? 1.0 : 0.0) : (b == 3) ? (j == 2 ? 1.0 : 0.0) : ((b == 2 && j == 1) ? -0.5 : 0.5);
-      const double cf = ga * gb;
-      if (cf != 0.0) {
-        const int t = 3 * i + j, ts = flip ? 8 - t : t;
-        float g = e0[(size_t)ts * tap_stride];
-        if (has_ks) g *= ks;
-        s += cf * (double)g;
-      }
-    }
-  }
-  return (float)s;
-}
-
 // Batched form: every packed panel of a network in ONE launch (a refresh after an Adam step used to be ~130 launches
 // of a few microseconds each for the generator).  Block -> job by binary search over the jobs' first blocks.
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
@@ -640,6 +615,55 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackJob* 
   }
   const PackJob J = jobs[lo];
   const unsigned b = blockIdx.x - J.blk0;
+  if (J.wino) {
+    // Winograd panel [nt][cc][16 frequencies][n][k]: one thread per (nt, cc, n, k) reads the nine taps once and writes
+    // all sixteen U = G g G^T elements (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; in double, each rounded once).
+    // g is what the direct kernel multiplies with: the fp32 source element (x kscale, rounded to fp32 first).
+    const unsigned cols = J.total / 16u, plane = (unsigned)(J.NT * J.CK);
+    for (unsigned i = b * 256u + threadIdx.x; i < cols; i += J.nblk * 256u) {
+      unsigned q = i;
+      const int k = (int)(q % J.CK);
+      q /= J.CK;
+      const int n = (int)(q % J.NT);
+      q /= J.NT;
+      const int cc = (int)(q % J.nCC);
+      const int nt = (int)(q / J.nCC);
+      const int kk = cc * J.CK + k, nn = nt * J.NT + n;
+      double g[3][3];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = 0.0;
+      if (kk < J.Kdim && nn < J.Ndim) {
+        const int ci = J.transpose ? nn : kk;
+        const int co = J.transpose ? kk : nn;
+        const float* e0 = J.src + (J.io ? ((size_t)co * J.srcI + ci) : ((size_t)ci * J.srcO + co));
+        const size_t ts_stride = (size_t)J.srcI * J.srcO;
+        const float ks = J.kscale ? J.kscale[kk] : 1.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          float v = e0[(size_t)(J.flip ? 8 - t : t) * ts_stride];
+          if (J.kscale) v *= ks;
+          g[t / 3][t % 3] = (double)v;
+        }
+      }
+      double tg[4][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        tg[0][c] = g[0][c];
+        tg[1][c] = 0.5 * (g[0][c] + g[1][c] + g[2][c]);
+        tg[2][c] = 0.5 * (g[0][c] - g[1][c] + g[2][c]);
+        tg[3][c] = g[2][c];
+      }
+      float* d = J.dst + (size_t)nt * J.nt_stride + ((size_t)cc * 16u) * plane + (size_t)n * J.CK + k;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        d[(4 * a + 0) * plane] = (float)tg[a][0];
+        d[(4 * a + 1) * plane] = (float)(0.5 * (tg[a][0] + tg[a][1] + tg[a][2]));
+        d[(4 * a + 2) * plane] = (float)(0.5 * (tg[a][0] - tg[a][1] + tg[a][2]));
+        d[(4 * a + 3) * plane] = (float)tg[a][2];
+      }
+    }
+    return;
+  }
   for (unsigned i = b * 256u + threadIdx.x; i < J.total; i += J.nblk * 256u) {
     unsigned q = i;
     const int k = (int)(q % J.CK);
@@ -657,13 +681,9 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackJob* 
       const int co = J.transpose ? kk : nn;
       const size_t eo = J.io ? ((size_t)co * J.srcI + ci) : ((size_t)ci * J.srcO + co);
       const size_t ts_stride = (size_t)J.srcI * J.srcO;
-      if (J.wino) {
-        v = wino_weight(J.src + eo, ts_stride, tap, J.flip, J.kscale ? J.kscale[kk] : 1.f, J.kscale != nullptr);
-      } else {
-        const int ts = J.flip ? (J.ntaps - 1 - tap) : tap;
-        v = J.src[(size_t)ts * ts_stride + eo];
-        if (J.kscale) v *= J.kscale[kk];
-      }
+      const int ts = J.flip ? (J.ntaps - 1 - tap) : tap;
+      v = J.src[(size_t)ts * ts_stride + eo];
+      if (J.kscale) v *= J.kscale[kk];
     }
     if (J.bf16 >= 2)
       store_split(J.dst, (size_t)nt * J.nt_stride * J.bf16, cc, tap, n, k, v, J.bf16, J.tapg, J.ntaps, J.NT, J.CK);
@@ -695,7 +715,7 @@ int dg_pack_job(const ConvPlan& pl, const float* src, int srcI, int srcO, int io
 unsigned dg_pack_layout(PackJob* jobs, int njobs) {
   unsigned b = 0;
   for (int i = 0; i < njobs; ++i) {
-    unsigned n = (jobs[i].total + 255u) / 256u;
+    unsigned n = ((jobs[i].wino ? jobs[i].total / 16u : jobs[i].total) + 255u) / 256u;
     if (n > 32u) n = 32u;            // grid-stride inside a job: ~1000 blocks for the whole generator
     if (n < 1u) n = 1u;
     jobs[i].blk0 = b;
