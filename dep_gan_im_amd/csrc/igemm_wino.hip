@@ -56,7 +56,8 @@ struct WnCfg {
   static constexpr int Z = 8 * ZPLANE;
   static constexpr int XTOT = PIXT * WN_XV;             // 16-byte pieces of a raw chunk
   static constexpr int XPIECES = (XTOT + 255) / 256;
-  static constexpr size_t LDS = sizeof(float) * (size_t)((RAW + V) > Z ? (RAW + V) : Z);
+  // two raw buffers (one barrier per chunk: a wave may stage chunk c + 1 while another still transforms chunk c)
+  static constexpr size_t LDS = sizeof(float) * (size_t)((2 * RAW + V) > Z ? (2 * RAW + V) : Z);
   static constexpr int WGS_PER_CU = (MT == 2) ? 2 : 3;
 };
 
@@ -72,8 +73,8 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
   constexpr int WN_RAW = C::RAW, WN_VPLANE = C::VPLANE, WN_ZPLANE = C::ZPLANE, WN_XTOT = C::XTOT, WN_XPIECES = C::XPIECES;
   typedef f32x16 acc_t;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* raw = smem;            // [(8 MT + 2) x 18][12]
-  float* V = smem + WN_RAW;     // [16][WN_VPLANE]
+  float* raw0 = smem;           // [2][(8 MT + 2) x 18][12]
+  float* V = smem + 2 * WN_RAW; // [16][WN_VPLANE]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -96,15 +97,17 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     xyx[i] = (ly << 16) | (lx << 8) | (part * 4);
   }
   const bool in_last = tid < (WN_XTOT % 256);
-  // transform task i: q = tid + 256 i -> channel group q & 1, transform row a = (q >> 1) & 3, tile q >> 3.
+  // transform task i of a lane: q = lane + 64 i -> channel group q & 1, tile q >> 1, transform row a = wave.
   // Row a of B^T d needs two of the tile's four halo rows:  a = 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3
   // = x + s y with (x, y) = rows (0,2) (1,2) (2,1) (1,3) and s = +1 for a = 1, else -1.
   int tA[MT], tB[MT], tV[MT];
   float tS[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int q = tid + 256 * i;
-    const int cg = q & 1, aa = (q >> 1) & 3, T = q >> 3;
+    // a wave transforms exactly the frequencies it multiplies (row a = wave): V needs no barrier between the transform
+    // and the MFMAs, only the LDS unit's in-order execution of the wave's own writes and reads
+    const int q = lane + 64 * i;
+    const int cg = q & 1, aa = wv, T = q >> 1;
     const int tyi = T >> 3, txi = T & 7;
     const int rA = (aa == 0) ? 0 : (aa == 2 ? 2 : 1), rB = (aa == 3) ? 3 : (aa == 2 ? 1 : 2);
     tA[i] = ((2 * tyi + rA) * WN_TW + 2 * txi) * WN_CKP + 4 * cg;
@@ -112,7 +115,7 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     tV[i] = (4 * aa) * WN_VPLANE + vslot(T, cg, aa);
     tS[i] = (aa == 1) ? 1.f : -1.f;
   }
-  const unsigned rawb0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)raw;
+  const unsigned rawb00 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)raw0;
   // fragments: A = V[f][32 mt + r][4h ..], B = panel[f][r][4h ..]
   int aoff[MT];
 #pragma unroll
@@ -164,7 +167,8 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         }
       }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+      const unsigned rawb0 = rawb00 + (unsigned)buf * (unsigned)(WN_RAW * sizeof(float));
 #pragma unroll
       for (int i = 0; i < WN_XPIECES - 1; ++i)
         *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((size_t)(rawb0 + xlb[i])) = xr[i];
@@ -189,10 +193,11 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
 #pragma unroll
       for (int f = 0; f < 4; ++f)
         bq[f] = *reinterpret_cast<const f32x4*>(wnt + (size_t)cc * (16 * NT * WN_CK) + f * (NT * WN_CK));
-      // every wave is past the barrier that followed the previous transform: the raw tile is free
-      if (!(ABL & 8)) commit();
-      __syncthreads();   // raw chunk cc complete; every wave is done with the MFMAs that read V of chunk cc - 1
+      // raw[cc & 1] was last read by the transform of chunk cc - 2: every wave is past the barrier of chunk cc - 1
+      if (!(ABL & 8)) commit(cc & 1);
+      __syncthreads();   // raw chunk cc complete -- the only barrier of the chunk
       if (!(ABL & 8) && cc + 1 < nCC) prefetch(cc + 1);
+      const float* raw = raw0 + (cc & 1) * WN_RAW;
       // ---- input transform: raw -> V ----
 #pragma unroll
       for (int i = 0; i < ((ABL & 2) ? 0 : MT); ++i) {
@@ -217,8 +222,7 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         *reinterpret_cast<f32x4*>(V + tV[i] + 2 * WN_VPLANE) = v2;
         *reinterpret_cast<f32x4*>(V + tV[i] + 3 * WN_VPLANE) = v3;
       }
-      __syncthreads();   // V of chunk cc complete
-      // ---- 16 GEMMs, this wave's four: 32 MFMAs ----
+      // ---- 16 GEMMs, this wave's four: 32 MFMAs (V rows of frequency row a = wave: written by this wave just above) ----
       f32x4 av[2][MT];
       auto load_a = [&](int f, f32x4* d) {
 #pragma unroll
@@ -334,10 +338,10 @@ static int wino_mt(const ConvArgs& a) {
   }
   if (a.ep.head_out) return 2;
   if (forced == 1 || forced == 2) return forced;
-  // 8-row tiles where 16-row tiles would leave CUs without a workgroup (measured: 16x16 images at batch 32, 256 items
-  // of 16 rows: 61.8 -> 57.9 us; equal within 1 % everywhere else, profiles/r03_conv_experiments.md)
-  const long items16 = (long)cdiv(a.W, 16) * cdiv(a.H, 16) * a.B * (a.Cout / 32);
-  return items16 <= 2L * dg_cu_count() ? 1 : 2;
+  // 8-row tiles, three workgroups per CU: with ONE barrier per chunk (wave-private transform) the third wave per SIMD
+  // pays -- sum over the step's twelve shapes 3246 us against 3335 us for 16-row tiles, never slower, up to 9 % faster
+  // where 16-row tiles leave CUs without a workgroup (profiles/r03_conv_experiments.md)
+  return 1;
 }
 
 template <int MT>
