@@ -26,6 +26,8 @@
 // igemm_conv; no groups.  Everything else stays on igemm_conv_kernel.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "epilogue.h"
 
@@ -73,8 +75,9 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
   constexpr int WN_RAW = C::RAW, WN_VPLANE = C::VPLANE, WN_ZPLANE = C::ZPLANE, WN_XTOT = C::XTOT, WN_XPIECES = C::XPIECES;
   typedef f32x16 acc_t;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* raw0 = smem;           // [2][(8 MT + 2) x 18][12]
-  float* V = smem + 2 * WN_RAW; // [16][WN_VPLANE]
+  // raw halo buffers [(8 MT + 2) x 18][12] x 2 and V [16][WN_VPLANE]; the Z planes of the epilogue alias all three
+  float* const rawp[2] = {smem, smem + WN_RAW};
+  float* V = smem + 2 * WN_RAW;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -115,7 +118,8 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     tV[i] = (4 * aa) * WN_VPLANE + vslot(T, cg, aa);
     tS[i] = (aa == 1) ? 1.f : -1.f;
   }
-  const unsigned rawb00 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)raw0;
+  const unsigned rawb[2] = {(unsigned)(size_t)(__attribute__((address_space(3))) float*)rawp[0],
+                            (unsigned)(size_t)(__attribute__((address_space(3))) float*)rawp[1]};
   // fragments: A = V[f][32 mt + r][4h ..], B = panel[f][r][4h ..]
   int aoff[MT];
 #pragma unroll
@@ -168,7 +172,7 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
       }
     };
     auto commit = [&](int buf) {
-      const unsigned rawb0 = rawb00 + (unsigned)buf * (unsigned)(WN_RAW * sizeof(float));
+      const unsigned rawb0 = buf ? rawb[1] : rawb[0];
 #pragma unroll
       for (int i = 0; i < WN_XPIECES - 1; ++i)
         *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((size_t)(rawb0 + xlb[i])) = xr[i];
@@ -177,17 +181,14 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
             xr[WN_XPIECES - 1];
     };
 
+    // no zeroing pass: the first MFMA of every accumulator (chunk 0, j = 0) takes a constant-zero C operand -- 64 MT
+    // vector moves per item less on a pipe where every vector instruction costs its issue time next to the MFMAs
     acc_t acc[4][MT];
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[f][mt][j] = 0.f;
 
     const float* wnt = a.w + (size_t)ntile * nCC * (16 * NT * WN_CK) + boff;
     if (!(ABL & 8)) prefetch(0);
-    for (int cc = 0; cc < nCC; ++cc) {
+    auto chunk = [&](const int cc, auto first_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;
       // this wave's weight fragments of the chunk: four frequencies x (32 channels x 8) -- in flight during the transform
       f32x4 bq[4];
 #pragma unroll
@@ -196,8 +197,10 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
       // raw[cc & 1] was last read by the transform of chunk cc - 2: every wave is past the barrier of chunk cc - 1
       if (!(ABL & 8)) commit(cc & 1);
       __syncthreads();   // raw chunk cc complete -- the only barrier of the chunk
+      // (issuing these loads in front of the barrier, with or without a barrier that leaves vmcnt alone, measured
+      // 1.5 ... 3 % slower)
       if (!(ABL & 8) && cc + 1 < nCC) prefetch(cc + 1);
-      const float* raw = raw0 + (cc & 1) * WN_RAW;
+      const float* raw = (cc & 1) ? rawp[1] : rawp[0];
       // ---- input transform: raw -> V ----
 #pragma unroll
       for (int i = 0; i < ((ABL & 2) ? 0 : MT); ++i) {
@@ -238,11 +241,22 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            if (!(ABL & 4)) acc[f][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[f][j], av[f & 1][mt][j], acc[f][mt], 0, 0, 0);
-            else acc[f][mt][j] += bq[f][j] * av[f & 1][mt][j];
+            if (!(ABL & 4)) {
+              if (FIRST && j == 0) {
+                const acc_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[f][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[f][j], av[f & 1][mt][j], zero, 0, 0, 0);
+              } else {
+                acc[f][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[f][j], av[f & 1][mt][j], acc[f][mt], 0, 0, 0);
+              }
+            } else {
+              if (FIRST && j == 0) acc[f][mt] = acc_t{};
+              acc[f][mt][j] += bq[f][j] * av[f & 1][mt][j];
+            }
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
+    };
+    chunk(0, std::true_type{});
+    for (int cc = 1; cc < nCC; ++cc) chunk(cc, std::false_type{});
 
     if (ABL & 1) {   // keep the accumulators alive with one store that never happens
       float sacc = 0.f;
@@ -257,8 +271,9 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
       continue;
     }
     // ---- output transform, first half (this wave's row a = wv: the four b's -> the two output columns q) ----
-    __syncthreads();   // every wave is done with V: the Z exchange may overwrite raw and V
-    {
+    // run from inside the fused epilogue (EPI_STAGE_LATE): after its per-item constant loads have been issued
+    auto zstage = [&]() {
+      __syncthreads();   // every wave is done with V: the Z exchange may overwrite raw and V
       float* zw = smem + (2 * wv) * WN_ZPLANE + r * WN_CP + 4 * h;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -275,11 +290,13 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
           *reinterpret_cast<f32x4*>(zw + mt * (32 * WN_CP) + 8 * g) = z0;
           *reinterpret_cast<f32x4*>(zw + WN_ZPLANE + mt * (32 * WN_CP) + 8 * g) = z1;
         }
-    }
+      __syncthreads();
+    };
     // second half inside the fused epilogue: pixel (py, px) of the wave's 4 x 16 block is output (py & 1, px & 1) of
     // tile (2 wv + py / 2, px / 2); even rows Z[0] + Z[1] + Z[2], odd rows Z[1] - Z[2] - Z[3]
-#define EPI_PRE_SYNC __syncthreads()
+#define EPI_PRE_SYNC
 #define EPI_STAGE
+#define EPI_STAGE_LATE zstage()
 #define EPI_NPASS (4 * MT)
 #define EPI_OYW (ty0 + 2 * MT * __builtin_amdgcn_readfirstlane(wv))
 #define EPI_FULL ((ty0 + C::TH <= a.H) && (tx0 + 16 <= a.W))
@@ -299,9 +316,13 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
 #undef EPI_FULL
 #undef EPI_OYW
 #undef EPI_NPASS
+#undef EPI_STAGE_LATE
 #undef EPI_STAGE
 #undef EPI_PRE_SYNC
-    if (PERS) __syncthreads();   // the next item's raw tile overwrites the Z planes
+    // the next item's first raw tile overwrites the Z planes (keeping raw buffer 0 apart from them -- 46.5 KB for 8-row
+    // tiles, still three workgroups per CU -- and dropping this barrier measured neutral: 3230 -> 3218 us over the
+    // twelve shapes, inside the run-to-run spread)
+    if (PERS) __syncthreads();
   } while (PERS && (id += gridDim.x) < nPix * nNTall);
 }
 
