@@ -10,15 +10,20 @@
 // what changes is the summation tree (measured against an fp64 convolution: 1.7 x the rounding error of the direct
 // kernel, both ~1e-7 of the output's range -- tests/test_gpu_ops.py).
 //
-// Mapping (one workgroup = 256 threads = 4 waves; item = 16 x 16 output pixels of one sample x 32 output channels):
-//   * the 16 x 16 tile is 8 x 8 = 64 Winograd tiles; the 16 "frequencies" (a, b) of the transform domain are 16
-//     independent GEMMs  M_f[tile][n] = sum_c V_f[tile][c] U_f[c][n]  (64 x Cin x 32);
-//   * wave w owns the frequencies a = w (b = 0..3): 4 frequencies x 2 MFMA row tiles (32 tiles each) of
-//     v_mfma_f32_32x32x2_f32 = 8 accumulators = 128 registers.  Its weight fragments U_f are nobody else's: they go
-//     from the packed panel [nt][chunk][f][n][8] straight into registers, never through LDS;
-//   * per chunk of 8 input channels: the 18 x 18 x 8 raw halo goes global -> registers -> LDS (as in igemm_conv), every
-//     thread transforms 2 x (tile, 4 channels, a) to four b128 rows of V[f][tile][8] in LDS (16 packed additions each),
-//     barrier, 32 MFMAs per wave with one b128 A-fragment read per 4 of them;
+// Mapping (one workgroup = 256 threads = 4 waves; item = 8 MT x 16 output pixels of one sample x 32 output channels;
+// MT = 1: 8-row tiles, 64 accumulator registers per wave, three workgroups per CU -- the default; MT = 2: 16-row tiles,
+// 128 registers, two per CU -- the form that carries the fused one-channel head):
+//   * the tile is 4 MT x 8 Winograd tiles (2 x 2 outputs each); the 16 "frequencies" (a, b) of the transform domain are
+//     16 independent GEMMs  M_f[tile][n] = sum_c V_f[tile][c] U_f[c][n]  (32 MT x Cin x 32);
+//   * wave w owns the frequencies a = w (b = 0..3): 4 frequencies x MT row tiles of v_mfma_f32_32x32x2_f32.  Its
+//     weight fragments U_f are nobody else's: from the packed panel [nt][chunk][f][n][8] straight into registers, never
+//     through LDS.  And it transforms exactly the V rows it multiplies: task = (tile, 4 channels) for row a = w, two
+//     halo rows x four columns in, four 16-byte rows of V out -- so V is wave-private and needs no barrier, only the LDS
+//     unit's in-order execution of the wave's own writes and reads;
+//   * per chunk of 8 input channels: the raw (8 MT + 2) x 18 x 8 halo goes global -> registers -> LDS (double-buffered;
+//     its completion is the ONE barrier of the chunk), transform (16 packed additions per task), 16 MT MFMAs per wave
+//     with one b128 A-fragment read per four of them.  V planes are XOR-swizzled (vslot): the LDS serves a b128 access
+//     eight lanes at a time out of 128 bytes of banks;
 //   * epilogue: each wave reduces its four b's to the two output columns in registers (Z[a][q] = row transform), the
 //     waves exchange Z through LDS, and the fused epilogue of igemm_conv (igemm_epilogue.inc, same text) fetches
 //     v = Z[0] + Z[1] + Z[2] (even rows) or Z[1] - Z[2] - Z[3] (odd rows) where it used to fetch one transposed value.
