@@ -145,7 +145,7 @@ static int u_noise_bwd(depgan_ctx* c, const float* z, int n) {
 // trunk, learning phase 1
 // ---------------------------------------------------------------------------
 static int u_bn_act(depgan_ctx* c, GLayer& L, int Ho, int Wo, int n, unsigned drop_seed) {
-  ProfScope ps(c, 2, 0.0);
+  ProfScope ps(c, 2, 0.0, "bn fwd: moments + affine / act");
   const double N = (double)n * Ho * Wo;
   DGCHECK(dg_col_moments(L.raw.view(), n, Ho, Wo, L.Cout, L.bmean, L.bvar, c->scratch, c->st));
   DGCHECK(dg_bn_train_prepare(L.gamma, L.beta, L.bmean, L.bvar, kBnEps, kBnMomentum, (float)(N / (N - 1.0)), L.mean,
@@ -173,7 +173,7 @@ static int u_bn_act(depgan_ctx* c, GLayer& L, int Ho, int Wo, int n, unsigned dr
 
 static int u_forward_train(depgan_ctx* c, const float* x, const float* z, int n, unsigned drop_seed) {
   {
-    ProfScope ps(c, 2, 0.0);
+    ProfScope ps(c, 2, 0.0, "noise mlp fwd");
     DGCHECK(u_noise_fwd(c, z, n));
   }
   for (size_t i = 0; i < c->gl.size(); ++i) {
@@ -195,7 +195,7 @@ static int u_forward_train(depgan_ctx* c, const float* x, const float* z, int n,
       DGCHECK(conv_launch(c, L.pf, a, 3));
       DGCHECK(u_bn_act(c, L, L.H, L.W, n, drop_seed));
     } else if (L.kind == G_POOL) {
-      ProfScope ps(c, 2, 0.0);
+      ProfScope ps(c, 2, 0.0, "maxpool");
       DGCHECK(dg_maxpool(c->gl[L.skip_of].out, L.out, n, L.H / 2, L.W / 2, L.Cout, c->st));
     } else if (L.kind == G_DECONV) {
       for (int t = 0; t < 4 && !deconv_fused(c, L, n); ++t) {
@@ -237,7 +237,7 @@ static int u_head_logits(depgan_ctx* c, int n) {
 // BN backward of one layer: dy (grad at the BN output, ReLU / FiLM already applied) -> dRAW in draw_tmp,
 // dgamma / dbeta written.  dyscale: constant factor still to be applied to dy (dropout's 1/(1-rate)).
 static int u_bn_bwd(depgan_ctx* c, GLayer& L, TView dy, int Ho, int Wo, int n, float dyscale, TView* draw) {
-  ProfScope ps(c, 2, 0.0);
+  ProfScope ps(c, 2, 0.0, "bn bwd: sums + dRAW");
   const double N = (double)n * Ho * Wo;
   *draw = make_view(c->draw_tmp.p, Ho, Wo, L.Cout);
   DGCHECK(dg_colsum_pair(dy, L.raw.view(), L.bmean, n, Ho, Wo, L.Cout, L.sums, c->scratch, c->st));
@@ -292,14 +292,14 @@ static int u_backward(depgan_ctx* c, const float* x, const float* z, int n) {
     } else if (L.kind == G_FILM) {
       TView du = make_view(c->du_tmp.p, L.H, L.W, L.Cout);
       {
-        ProfScope ps(c, 2, 0.0);
+        ProfScope ps(c, 2, 0.0, "film bwd");
         DGCHECK(dg_film_bwd(L.dout.p, L.u.p, c->na.heads + L.col_mul, c->na.heads + L.col_add, 1024, du.p,
                             c->dheads + L.col_mul, c->dheads + L.col_add, n, (long)L.H * L.W, L.Cout, c->scratch,
                             c->st));
       }
       DGCHECK(u_conv_bwd(c, L, (size_t)i, x, du, L.dout, n, 1.0f));
     } else if (L.kind == G_POOL) {
-      ProfScope ps(c, 2, 0.0);
+      ProfScope ps(c, 2, 0.0, "unpool+mask");
       DGCHECK(dg_unpool_mask(L.pool_dsrc, c->gl[L.skip_of].out, L.pool_skipgrad, L.pool_dst, n, L.H / 2, L.W / 2,
                              L.Cout, c->st));
     } else if (L.kind == G_DECONV) {
@@ -310,7 +310,7 @@ static int u_backward(depgan_ctx* c, const float* x, const float* z, int n) {
       DGCHECK(deconv_bwd_data(c, L, draw, n));
     }
   }
-  ProfScope ps(c, 2, 0.0);
+  ProfScope ps(c, 2, 0.0, "noise mlp bwd");
   return u_noise_bwd(c, z, n);
 }
 
@@ -334,7 +334,7 @@ static int u_forward_infer(depgan_ctx* c, const float* x, const float* z, int n)
 int uresnet_predict(depgan_ctx* c, const float* x, const float* z, float* out, int n) {
   DGCHECK(u_forward_infer(c, x, z, n));
   const long P = (long)n * c->cfg.height * c->cfg.width;
-  ProfScope ps(c, 2, 0.0);
+  ProfScope ps(c, 2, 0.0, "softmax");
   return dg_softmax4(c->logits, out, P, c->st);
 }
 
@@ -360,7 +360,7 @@ static int u_grads(depgan_ctx* c, const float* x, const float* z, const float* l
   DGCHECK(u_forward_train(c, x, z, n, drop_seed));
   DGCHECK(u_head_logits(c, n));
   {
-    ProfScope ps(c, 2, 0.0);
+    ProfScope ps(c, 2, 0.0, "softmax + cross-entropy");
     DGCHECK(dg_softmax_ce4(c->logits, labels, c->attr.p, c->dz, c->loss_dev, P, c->scratch, c->st));
   }
   DGCHECK(u_backward(c, x, z, n));
@@ -390,7 +390,7 @@ int depgan_uresnet_eval(depgan_ctx* c, const float* x, const float* z, const flo
   const long P = (long)n * c->cfg.height * c->cfg.width;
   DGCHECK(u_forward_infer(c, x, z, n));
   {
-    ProfScope ps(c, 2, 0.0);
+    ProfScope ps(c, 2, 0.0, "softmax + cross-entropy");
     DGCHECK(dg_softmax_ce4(c->logits, labels, c->attr.p, c->dz, c->loss_dev, P, c->scratch, c->st));
   }
   return u_loss_to_host(c, P, loss_host);

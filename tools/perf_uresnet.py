@@ -21,3 +21,12 @@ for i in range(3): eng.uresnet(x, z, lab, "step", drop_seed=30 + i)
 for k, nm in ((0, "mfma conv"), (1, "mfma wgrad"), (2, "other")):
     t, n, fl = eng.profile_read(k)
     print("  class %-10s %7.2f ms/step  %4d launches  %6.1f TF/s" % (nm, t / 3, n // 3, fl / t / 1e9 if t else 0))
+if len(sys.argv) > 2:   # per-label table of the `other` class: python tools/perf_uresnet.py 32 <csv>
+    import csv, collections
+    eng.profile_dump(sys.argv[2])
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(sys.argv[2])):
+        if int(r["class"]) == 2:
+            a = acc[r["label"]]; a[0] += 1; a[1] += float(r["ms"])
+    for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:25]:
+        print("  other %-34s %3d launches/step %7.3f ms/step" % (k, v[0] // 3, v[1] / 3))
