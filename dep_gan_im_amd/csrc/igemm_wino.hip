@@ -20,10 +20,11 @@
 //     through LDS.  And it transforms exactly the V rows it multiplies: task = (tile, 4 channels) for row a = w, two
 //     halo rows x four columns in, four 16-byte rows of V out -- so V is wave-private and needs no barrier, only the LDS
 //     unit's in-order execution of the wave's own writes and reads;
-//   * per chunk of 8 input channels: the raw (8 MT + 2) x 18 x 8 halo goes global -> registers -> LDS (double-buffered;
-//     its completion is the ONE barrier of the chunk), transform (16 packed additions per task), 16 MT MFMAs per wave
-//     with one b128 A-fragment read per four of them.  V planes are XOR-swizzled (vslot): the LDS serves a b128 access
-//     eight lanes at a time out of 128 bytes of banks;
+//   * per chunk of 8 input channels: the raw (8 MT + 2) x 18 x 8 halo is copied global -> LDS by the DMA path
+//     (buffer_load_dwordx4 ... lds: no registers, no ds_write pass, asynchronous; double-buffered, issued a whole chunk
+//     ahead; its completion is the ONE barrier of the chunk), transform (16 packed additions per task), 16 MT MFMAs per
+//     wave with one b128 A-fragment read per four of them.  The raw image and the V planes are XOR-swizzled (rslot,
+//     vslot): the LDS serves a b128 access eight lanes at a time out of 128 bytes of banks;
 //   * epilogue: each wave reduces its four b's to the two output columns in registers (Z[a][q] = row transform), the
 //     waves exchange Z through LDS, and the fused epilogue of igemm_conv (igemm_epilogue.inc, same text) fetches
 //     v = Z[0] + Z[1] + Z[2] (even rows) or Z[1] - Z[2] - Z[3] (odd rows) where it used to fetch one transposed value.
@@ -38,7 +39,7 @@
 
 namespace {
 
-constexpr int WN_CK = 8, WN_CKP = 12;           // channels per chunk; floats per raw halo pixel (48 B rows)
+constexpr int WN_CK = 8;                         // channels per chunk (one b128 fragment read = 4 MFMAs of 2 channels)
 constexpr int WN_TW = 18;                       // halo columns of a 16-pixel-wide tile
 constexpr int WN_CP = 36;                       // floats per tile row of the Z exchange (32 channels + 4)
 constexpr int WN_XV = WN_CK / 4;
@@ -52,7 +53,15 @@ struct WnCfg {
   static constexpr int TH = 8 * MT;                     // output rows per workgroup
   static constexpr int NTILE = 32 * MT;                 // Winograd tiles per workgroup
   static constexpr int PIXT = (TH + 2) * WN_TW;         // raw halo pixels
-  static constexpr int RAW = PIXT * WN_CKP;             // floats
+  // The raw halo chunk is copied global -> LDS by the DMA path (buffer_load_dwordx4 ... lds: no VGPR destination, no
+  // ds_write pass, asynchronous): a wave-instruction writes 64 lanes x 16 B lane-linearly, so the LDS image is the
+  // unpadded [pixel][8 channels] one, in whole rounds of 256 pieces.  Which piece a lane FETCHES is free, and that is
+  // where the bank swizzle goes (rslot): logical piece (pixel, half) lives in slot (2 pixel + half) ^ (bit 2 of pixel
+  // << 1), so the transform's reads -- eight lanes = four tiles x two channel halves, 64 B apart -- hit eight different
+  // 16-byte slots of the 128-byte bank window.
+  static constexpr int XTOT = PIXT * WN_XV;             // 16-byte pieces of a raw chunk
+  static constexpr int NXP = (XTOT + 255) / 256;        // DMA instructions per wave and chunk
+  static constexpr int RAW = NXP * 256 * 4;             // floats
   // one frequency: tiles x 8 channels, unpadded; its 16-byte slots are XOR-swizzled (vslot below): the LDS serves a
   // b128 access eight lanes at a time out of 128 bytes of banks, so eight consecutive lanes must hit eight different
   // slots modulo 8 -- lanes r and r + 4 of a fragment read (32-byte rows) and the four a's of a transform write
@@ -61,8 +70,6 @@ struct WnCfg {
   static constexpr int V = 16 * VPLANE;
   static constexpr int ZPLANE = NTILE * WN_CP + 32;     // one (a, q): +128 B so that q = 0 / 1 of a pixel pair differ in bank group
   static constexpr int Z = 8 * ZPLANE;
-  static constexpr int XTOT = PIXT * WN_XV;             // 16-byte pieces of a raw chunk
-  static constexpr int XPIECES = (XTOT + 255) / 256;
   // two raw buffers (one barrier per chunk: a wave may stage chunk c + 1 while another still transforms chunk c)
   static constexpr size_t LDS = sizeof(float) * (size_t)((2 * RAW + V) > Z ? (2 * RAW + V) : Z);
   static constexpr int WGS_PER_CU = (MT == 2) ? 2 : 3;
@@ -70,6 +77,9 @@ struct WnCfg {
 
 // ABL: ablation bits for tools/time_wino.py (0 = the product kernel; the others are compiled with
 // -DDEPGAN_WINO_ABLATIONS only): 1 no epilogue, 2 no input transform, 4 no MFMAs, 8 no raw staging
+// 16-byte slot of the raw LDS image that holds logical piece (pixel, channel half); an involution on slot indices
+static __device__ __forceinline__ int rslot(int pix, int half) { return (2 * pix + half) ^ (((pix >> 2) & 1) << 1); }
+
 // float offset inside a V plane of 16-byte slot (tile T, channel half cg) of the frequencies of transform row a
 static __device__ __forceinline__ int vslot(int T, int cg, int a) { return ((2 * T + cg) ^ ((T >> 2) & 1) ^ (a << 1)) << 2; }
 
@@ -77,11 +87,12 @@ template <int MT, bool PERS, bool HEAD, int ABL = 0>
 static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
   typedef WnCfg<MT> C;
   constexpr int MF = 32, NT = 32;
-  constexpr int WN_RAW = C::RAW, WN_VPLANE = C::VPLANE, WN_ZPLANE = C::ZPLANE, WN_XTOT = C::XTOT, WN_XPIECES = C::XPIECES;
+  constexpr int WN_RAW = C::RAW, WN_VPLANE = C::VPLANE, WN_ZPLANE = C::ZPLANE, WN_XTOT = C::XTOT, NXP = C::NXP;
   typedef f32x16 acc_t;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // raw halo buffers [(8 MT + 2) x 18][12] x 2 and V [16][WN_VPLANE]; the Z planes of the epilogue alias all three
-  float* const rawp[2] = {smem, smem + WN_RAW};
+  float* const raw0 = smem;
+  float* const raw1 = smem + WN_RAW;
   float* V = smem + 2 * WN_RAW;
 
   const int tid = threadIdx.x;
@@ -92,23 +103,24 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
   const int nCC = a.Cin / WN_CK;
 
   // ---- per-thread geometry, once per workgroup ----
-  // raw staging piece i: slot q = tid + 256 i -> halo pixel q / 2, channel half q & 1
-  unsigned xgb[WN_XPIECES], xlb[WN_XPIECES];
-  int xyx[WN_XPIECES];
+  // raw staging: DMA piece i of this thread fills LDS slot q = tid + 256 i with logical piece rslot^-1(q) = rslot of it
+  // (an involution): byte offset from the halo origin, or an out-of-range offset for the padding slots behind the halo
+  // tile (the hardware returns zeros for those, as for out-of-image pixels)
+  constexpr int SENT = (int)0x80000000;
+  int xvo[NXP], xyx[NXP];
 #pragma unroll
-  for (int i = 0; i < WN_XPIECES; ++i) {
-    const int q = min(tid + i * 256, WN_XTOT - 1);
-    const int pix = q / WN_XV, part = q - pix * WN_XV;
+  for (int i = 0; i < NXP; ++i) {
+    const int q = tid + i * 256;
+    const int lq = q ^ (((q >> 3) & 1) << 1);
+    const int pix = lq >> 1, part = lq & 1;
     const int ly = pix / WN_TW, lx = pix - ly * WN_TW;
-    xgb[i] = 4u * (unsigned)(ly * (int)a.in.sY + lx * (int)a.in.sX + part * 4);
-    xlb[i] = 4u * (unsigned)(pix * WN_CKP + part * 4);
-    xyx[i] = (ly << 16) | (lx << 8) | (part * 4);
+    xvo[i] = (q < WN_XTOT) ? 4 * (ly * (int)a.in.sY + lx * (int)a.in.sX + part * 4) : SENT;
+    xyx[i] = (ly << 8) | lx;
   }
-  const bool in_last = tid < (WN_XTOT % 256);
   // transform task i of a lane: q = lane + 64 i -> channel group q & 1, tile q >> 1, transform row a = wave.
   // Row a of B^T d needs two of the tile's four halo rows:  a = 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3
   // = x + s y with (x, y) = rows (0,2) (1,2) (2,1) (1,3) and s = +1 for a = 1, else -1.
-  int tA[MT], tB[MT], tV[MT];
+  int tA[MT][4], tB[MT][4], tV[MT];
   float tS[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -118,13 +130,15 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     const int cg = q & 1, aa = wv, T = q >> 1;
     const int tyi = T >> 3, txi = T & 7;
     const int rA = (aa == 0) ? 0 : (aa == 2 ? 2 : 1), rB = (aa == 3) ? 3 : (aa == 2 ? 1 : 2);
-    tA[i] = ((2 * tyi + rA) * WN_TW + 2 * txi) * WN_CKP + 4 * cg;
-    tB[i] = ((2 * tyi + rB) * WN_TW + 2 * txi) * WN_CKP + 4 * cg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tA[i][j] = 4 * rslot((2 * tyi + rA) * WN_TW + 2 * txi + j, cg);
+      tB[i][j] = 4 * rslot((2 * tyi + rB) * WN_TW + 2 * txi + j, cg);
+    }
     tV[i] = (4 * aa) * WN_VPLANE + vslot(T, cg, aa);
     tS[i] = (aa == 1) ? 1.f : -1.f;
   }
-  const unsigned rawb[2] = {(unsigned)(size_t)(__attribute__((address_space(3))) float*)rawp[0],
-                            (unsigned)(size_t)(__attribute__((address_space(3))) float*)rawp[1]};
+  const int wbase = __builtin_amdgcn_readfirstlane(wv * 256);   // this wave's float offset inside a 256-piece round
   // fragments: A = V[f][32 mt + r][4h ..], B = panel[f][r][4h ..]
   int aoff[MT];
 #pragma unroll
@@ -158,32 +172,36 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
       }
       return (long)cc * WN_CK;
     };
-    f32x4 xr[WN_XPIECES];
-    auto prefetch = [&](int cc) {
-      const char* src = halo0 + 4 * coff(cc);   // only dereferenced through in-image offsets
+    // descriptor at the pixel one row and one column before the image origin: every in-image piece has a non-negative
+    // offset from it
+    const float* const xorg = a.in.p - ((long)a.in.sY + (long)a.in.sX);
+    const unsigned long long xu = (unsigned long long)xorg;
+    // (unsigned locals: readfirstlane returns int, and a low half with bit 31 set would sign-extend into the high one)
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xu), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xu >> 32));
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)xhi << 32) | xlo), 0, 0x7FFFFFFF, 0x00020000);
+    const int xso0 = 4 * (b * (int)a.in.sB + ty0 * (int)a.in.sY + tx0 * (int)a.in.sX);
+    auto stage_dma = [&](int cc, int buf) {   // chunk cc -> raw buffer buf
+      const int xso = xso0 + 4 * (int)coff(cc);
+      float* xs = (buf ? raw1 : raw0) + wbase;
       if (interior) {
 #pragma unroll
-        for (int i = 0; i < WN_XPIECES - 1; ++i) xr[i] = *reinterpret_cast<const f32x4*>(src + xgb[i]);
-        if (in_last) xr[WN_XPIECES - 1] = *reinterpret_cast<const f32x4*>(src + xgb[WN_XPIECES - 1]);
+        for (int i = 0; i < NXP; ++i) {
+          // (a plain int local: with a type-dependent argument such as xvo[i] hipcc drops the host-side instantiation
+          // of the kernel without a diagnostic)
+          const int vo = xvo[i];
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + i * 1024), 16, vo,
+                                                   xso, 0, 0);
+        }
       } else {
 #pragma unroll
-        for (int i = 0; i < WN_XPIECES; ++i) {
-          const int iy = ty0 + (xyx[i] >> 16) - 1, ix = tx0 + ((xyx[i] >> 8) & 255) - 1;
-          const bool ok = (i < WN_XPIECES - 1 || in_last) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (ok) v = *reinterpret_cast<const f32x4*>(src + xgb[i]);
-          xr[i] = v;
+        for (int i = 0; i < NXP; ++i) {
+          const int iy = ty0 + (xyx[i] >> 8) - 1, ix = tx0 + (xyx[i] & 255) - 1;
+          const int vo = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? xvo[i] : SENT;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + i * 1024), 16, vo,
+                                                   xso, 0, 0);
         }
       }
-    };
-    auto commit = [&](int buf) {
-      const unsigned rawb0 = buf ? rawb[1] : rawb[0];
-#pragma unroll
-      for (int i = 0; i < WN_XPIECES - 1; ++i)
-        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((size_t)(rawb0 + xlb[i])) = xr[i];
-      if (in_last)
-        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((size_t)(rawb0 + xlb[WN_XPIECES - 1])) =
-            xr[WN_XPIECES - 1];
     };
 
     // no zeroing pass: the first MFMA of every accumulator (chunk 0, j = 0) takes a constant-zero C operand -- 64 MT
@@ -191,7 +209,7 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     acc_t acc[4][MT];
 
     const float* wnt = a.w + (size_t)ntile * nCC * (16 * NT * WN_CK) + boff;
-    if (!(ABL & 8)) prefetch(0);
+    if (!(ABL & 8)) stage_dma(0, 0);
     auto chunk = [&](const int cc, auto first_tag) {
       constexpr bool FIRST = decltype(first_tag)::value;
       // this wave's weight fragments of the chunk: four frequencies x (32 channels x 8) -- in flight during the transform
@@ -199,21 +217,21 @@ static __device__ __forceinline__ void wino_body(const ConvArgs& a) {
 #pragma unroll
       for (int f = 0; f < 4; ++f)
         bq[f] = *reinterpret_cast<const f32x4*>(wnt + (size_t)cc * (16 * NT * WN_CK) + f * (NT * WN_CK));
-      // raw[cc & 1] was last read by the transform of chunk cc - 2: every wave is past the barrier of chunk cc - 1
-      if (!(ABL & 8)) commit(cc & 1);
-      __syncthreads();   // raw chunk cc complete -- the only barrier of the chunk
-      // (issuing these loads in front of the barrier, with or without a barrier that leaves vmcnt alone, measured
-      // 1.5 ... 3 % slower)
-      if (!(ABL & 8) && cc + 1 < nCC) prefetch(cc + 1);
-      const float* raw = (cc & 1) ? rawp[1] : rawp[0];
+      // this wave's DMA pieces of chunk cc (issued a whole chunk ago) and its weight fragments have landed ... (the
+      // compiler does not know that the DMA writes LDS: the wait is explicit)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // ... and so have everybody else's -- the only barrier of the chunk
+      // raw[(cc + 1) & 1] was last read by the transform of chunk cc - 1: every wave is past this chunk's barrier
+      if (!(ABL & 8) && cc + 1 < nCC) stage_dma(cc + 1, (cc + 1) & 1);
+      const float* raw = (cc & 1) ? raw1 : raw0;
       // ---- input transform: raw -> V ----
 #pragma unroll
       for (int i = 0; i < ((ABL & 2) ? 0 : MT); ++i) {
         f32x4 tc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(raw + tA[i] + j * WN_CKP);
-          const f32x4 y = *reinterpret_cast<const f32x4*>(raw + tB[i] + j * WN_CKP);
+          const f32x4 x = *reinterpret_cast<const f32x4*>(raw + tA[i][j]);
+          const f32x4 y = *reinterpret_cast<const f32x4*>(raw + tB[i][j]);
 #pragma unroll
           for (int k = 0; k < 4; ++k) tc[j][k] = fmaf(y[k], tS[i], x[k]);   // exact: s = +-1
         }
