@@ -54,6 +54,47 @@ def _engine(img, B, PG, PD1, PD2, **kw):
 SPLIT = pytest.mark.parametrize("split", [0, 6], ids=["native", "split6"])
 
 
+def test_winograd_and_direct_convolutions_agree_through_the_model(lib, tmp_path):
+    """The 3x3 layers run as Winograd F(2x2,3x3) by default (csrc/igemm_wino.hip) and as the direct implicit GEMM with
+    DEPGAN_WINOGRAD=0: two summation trees over the same fp32 operands.  Same weights and inputs through both: forward
+    outputs, the six generator-loss scalars, critic outputs and -- on inputs whose decisions (ReLU / pool arg-max) the two
+    paths share, which the noisy inputs here make overwhelmingly likely but not certain, hence relative L2 -- the
+    gradients of all three networks; the profile shows which kernels ran."""
+    img, B = 128, 2
+    PG, PD1, PD2, x, y2, z, ep = _setup(img, B, 41, noisy=True)
+
+    def run(wino):
+        os.environ["DEPGAN_WINOGRAD"] = "1" if wino else "0"
+        try:
+            eng = _engine(img, B, PG, PD1, PD2)
+        finally:
+            del os.environ["DEPGAN_WINOGRAD"]
+        eng.profile(True)
+        fwd = eng.g_forward(x, z).cpu().numpy()
+        eng.profile(False)
+        csv = str(tmp_path / ("prof_w%d.csv" % wino))
+        eng.profile_dump(csv)
+        kernels = open(csv).read()
+        d = eng.d_forward("D_y2", y2).cpu().numpy()
+        gl = eng.generator(x, y2, z, "grads")
+        gG = eng.get_grads("G")
+        eng.critic("D_y2", y2, x, z, ep, update=False)
+        gD = eng.get_grads("D_y2")
+        eng.close()
+        return fwd, kernels, d, gl, gG, gD
+
+    f1, k1, d1, l1, gG1, gD1 = run(True)
+    f0, k0, d0, l0, gG0, gD0 = run(False)
+    assert "wino_conv" in k1 and "wino_conv" not in k0, (k1[:300], k0[:300])
+    print("winograd vs direct: forward %.2e, critic %.2e, loss scalars %.2e" % (rel(f1, f0), rel(d1, d0), srel(l1, l0)))
+    assert rel(f1, f0) < 2e-5 and rel(d1, d0) < 2e-5 and srel(l1, l0) < 1e-4
+    for name, a_, b_ in (("G", gG1, gG0), ("D_y2", gD1, gD0)):
+        num = np.sqrt(sum(((a_[k].astype(np.float64) - b_[k]) ** 2).sum() for k in b_))
+        den = np.sqrt(sum((b_[k].astype(np.float64) ** 2).sum() for k in b_))
+        print("winograd vs direct: %s gradient rel-L2 %.2e" % (name, num / den))
+        assert num / den < 5e-3, (name, num / den)
+
+
 def test_fused_head_matches_the_separate_launch(lib, tmp_path):
     """gen_segmentation (1x1 to one channel + tanh, GT:494-495) rides in gen_17's convolution epilogue at full size
     (igemm_conv_head_kernel).  A/B against the same library with DEPGAN_HEAD_FUSED=0 (the separate dg_head_fwd launch)
