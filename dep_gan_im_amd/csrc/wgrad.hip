@@ -60,13 +60,20 @@ struct WDmaCfg {
   static constexpr int NXP = (XTOT + 255) / 256, NDP = DTOT / 256;   // DMA instructions per wave per tile
   static constexpr int XBUF = NXP * 256 * 4, DBUF = DTOT * 4, BUF = XBUF + DBUF;   // floats
   static constexpr size_t LDS_TILES = (size_t)2 * BUF * sizeof(float);
-  static constexpr size_t LDS_RED = (size_t)TPW * 4 * MF * MF * sizeof(float);   // every tap's 4 wave partials
+  // 8-row tiles of the 3x3 / 32-channel form: two sets of tile buffers (80 KB) fit a CU twice, so TWO workgroups share
+  // it -- a second wave per SIMD multiplies while the first one waits at a barrier or for its DMA.  Its final sum of the
+  // 4 waves then goes through LDS three taps at a time (48 KB) instead of all nine (144 KB); every other form keeps one
+  // round and its launch bound.
+  static constexpr bool TWO_PER_CU = (MF == 32 && KS == 3 && TH == 8);
+  static constexpr int RT = TWO_PER_CU ? 3 : TPW;
+  static constexpr size_t LDS_RED = (size_t)RT * 4 * MF * MF * sizeof(float);
   static constexpr size_t LDS_BYTES = LDS_TILES > LDS_RED ? LDS_TILES : LDS_RED;
+  static constexpr int WGS_PER_CU = TWO_PER_CU ? 2 : 1;
   static_assert(DTOT % 256 == 0, "dy tile must be whole wave-instructions");
 };
 
 template <int MF, int KS, int TPW, int TH>
-__global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, (WDmaCfg<MF, KS, TPW, TH>::WGS_PER_CU)) void wgrad_dma_kernel(const WgradArgs a) {
   typedef WDmaCfg<MF, KS, TPW, TH> C;
   constexpr int PAD = KS / 2, TW = C::TW, NTAPS = KS * KS, NGT = NTAPS / TPW;
   constexpr int KM = 64 / MF, PW = TH * 4, KSTEPS = PW / KM, V = C::V;
@@ -302,24 +309,28 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     }
   }
 
-  // ---- sum the 4 waves through LDS and write one slab per workgroup: all taps in one pass (two barriers) ----
-  float* red = smem;  // [TPW][4][MF*MF]
+  // ---- sum the 4 waves through LDS and write one slab per workgroup, RT taps per round (two barriers each) ----
+  constexpr int RT = C::RT;
+  float* red = smem;  // [RT][4][MF*MF]
   const size_t slab = (size_t)NTAPS * a.Cin * a.Cout;
   float* pout = a.part + (size_t)chunk * slab;
-  __syncthreads();    // every wave is done with the tile buffers
 #pragma unroll
-  for (int tl = 0; tl < TPW; ++tl)
+  for (int t0 = 0; t0 < TPW; t0 += RT) {
+    __syncthreads();    // every wave is done with the tile buffers / with the previous round
 #pragma unroll
-    for (int j = 0; j < MfmaW<MF>::NREG; ++j)
-      red[(tl * 4 + wv) * MF * MF + MfmaW<MF>::row(j, h) * MF + r] = acc[tl][j];
-  __syncthreads();
-  for (int q = tid; q < TPW * MF * MF; q += 256) {
-    const int tl = q / (MF * MF), e = q % (MF * MF);
-    const float* rt = red + tl * 4 * MF * MF;
-    const float sum = (rt[e] + rt[MF * MF + e]) + (rt[2 * MF * MF + e] + rt[3 * MF * MF + e]);
-    const int tap = tg * TPW + tl;
-    const int ci = ci0 + e / MF, co = co0 + e % MF;
-    if (ci < a.Cin && co < a.Cout) pout[((size_t)tap * a.Cin + ci) * a.Cout + co] = sum;
+    for (int tl = 0; tl < RT; ++tl)
+#pragma unroll
+      for (int j = 0; j < MfmaW<MF>::NREG; ++j)
+        red[(tl * 4 + wv) * MF * MF + MfmaW<MF>::row(j, h) * MF + r] = acc[t0 + tl][j];
+    __syncthreads();
+    for (int q = tid; q < RT * MF * MF; q += 256) {
+      const int tl = q / (MF * MF), e = q % (MF * MF);
+      const float* rt = red + tl * 4 * MF * MF;
+      const float sum = (rt[e] + rt[MF * MF + e]) + (rt[2 * MF * MF + e] + rt[3 * MF * MF + e]);
+      const int tap = tg * TPW + t0 + tl;
+      const int ci = ci0 + e / MF, co = co0 + e % MF;
+      if (ci < a.Cin && co < a.Cout) pout[((size_t)tap * a.Cin + ci) * a.Cout + co] = sum;
+    }
   }
   if (do_cs) {
     // fold the 64 / MF pixel-parity lanes of each channel and the 4 waves, in a fixed order
@@ -342,6 +353,16 @@ struct WVar {
   size_t lds;
 };
 
+// 3x3 / 32-channel form on 8-row tiles, two workgroups per CU (DEPGAN_WGRAD_TH8=0: 16-row tiles, one per CU)
+static bool wgrad_th8() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("DEPGAN_WGRAD_TH8");
+    on = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return on != 0;
+}
+
 static void pick_variant(int KS, int Cin, int Cout, WVar* v) {
   v->KS = KS;
   v->MF = (Cin % 32 == 0 && Cout % 32 == 0) ? 32 : 16;
@@ -351,8 +372,9 @@ static void pick_variant(int KS, int Cin, int Cout, WVar* v) {
     v->TPW = 5;
     v->TH = 8;
   }
+  if (KS == 3 && v->MF == 32 && wgrad_th8()) v->TH = 8;
   v->lds = 0;
-  if (KS == 3 && v->MF == 32) v->lds = WDmaCfg<32, 3, 9, 16>::LDS_BYTES;
+  if (KS == 3 && v->MF == 32) v->lds = v->TH == 8 ? WDmaCfg<32, 3, 9, 8>::LDS_BYTES : WDmaCfg<32, 3, 9, 16>::LDS_BYTES;
   if (KS == 3 && v->MF == 16) v->lds = WDmaCfg<16, 3, 9, 16>::LDS_BYTES;
   if (KS == 5 && v->MF == 32) v->lds = WDmaCfg<32, 5, 5, 8>::LDS_BYTES;
   if (KS == 5 && v->MF == 16) v->lds = WDmaCfg<16, 5, 25, 16>::LDS_BYTES;
@@ -420,6 +442,7 @@ int dg_wgrad(int KS, const WgradArgs& a_in, int* nchunks_out, hipStream_t st) {
   a.nTiles = nTiles;
   a.tilesPerChunk = tpc;
   *nchunks_out = nch;
+  if (KS == 3 && v.MF == 32 && v.TH == 8) return launch_wgrad_dma<32, 3, 9, 8>(a, nch, gy, st);
   if (KS == 3 && v.MF == 32) return launch_wgrad_dma<32, 3, 9, 16>(a, nch, gy, st);
   if (KS == 3 && v.MF == 16) return launch_wgrad_dma<16, 3, 9, 16>(a, nch, gy, st);
   if (KS == 5 && v.MF == 32) return launch_wgrad_dma<32, 5, 5, 8>(a, nch, gy, st);
