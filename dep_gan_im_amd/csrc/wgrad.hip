@@ -64,8 +64,8 @@ struct WDmaCfg {
   // it -- a second wave per SIMD multiplies while the first one waits at a barrier or for its DMA.  Its final sum of the
   // 4 waves then goes through LDS three taps at a time (48 KB) instead of all nine (144 KB); every other form keeps one
   // round and its launch bound.
-  static constexpr bool TWO_PER_CU = (MF == 32 && KS == 3 && TH == 8);
-  static constexpr int RT = TWO_PER_CU ? 3 : TPW;
+  static constexpr bool TWO_PER_CU = (MF == 32 && KS == 3 && TH == 8) || (MF == 32 && KS == 5 && TH == 4);
+  static constexpr int RT = TWO_PER_CU ? (KS == 3 ? 3 : 1) : TPW;
   static constexpr size_t LDS_RED = (size_t)RT * 4 * MF * MF * sizeof(float);
   static constexpr size_t LDS_BYTES = LDS_TILES > LDS_RED ? LDS_TILES : LDS_RED;
   static constexpr int WGS_PER_CU = TWO_PER_CU ? 2 : 1;
@@ -370,13 +370,13 @@ static void pick_variant(int KS, int Cin, int Cout, WVar* v) {
   v->TPW = KS * KS;
   if (KS == 5 && v->MF == 32) {
     v->TPW = 5;
-    v->TH = 8;
+    v->TH = wgrad_th8() ? 4 : 8;
   }
   if (KS == 3 && v->MF == 32 && wgrad_th8()) v->TH = 8;
   v->lds = 0;
   if (KS == 3 && v->MF == 32) v->lds = v->TH == 8 ? WDmaCfg<32, 3, 9, 8>::LDS_BYTES : WDmaCfg<32, 3, 9, 16>::LDS_BYTES;
   if (KS == 3 && v->MF == 16) v->lds = WDmaCfg<16, 3, 9, 16>::LDS_BYTES;
-  if (KS == 5 && v->MF == 32) v->lds = WDmaCfg<32, 5, 5, 8>::LDS_BYTES;
+  if (KS == 5 && v->MF == 32) v->lds = v->TH == 4 ? WDmaCfg<32, 5, 5, 4>::LDS_BYTES : WDmaCfg<32, 5, 5, 8>::LDS_BYTES;
   if (KS == 5 && v->MF == 16) v->lds = WDmaCfg<16, 5, 25, 16>::LDS_BYTES;
   if (KS == 1 && v->MF == 32) v->lds = WDmaCfg<32, 1, 1, 16>::LDS_BYTES;
   if (KS == 1 && v->MF == 16) v->lds = WDmaCfg<16, 1, 1, 16>::LDS_BYTES;
@@ -445,6 +445,7 @@ int dg_wgrad(int KS, const WgradArgs& a_in, int* nchunks_out, hipStream_t st) {
   if (KS == 3 && v.MF == 32 && v.TH == 8) return launch_wgrad_dma<32, 3, 9, 8>(a, nch, gy, st);
   if (KS == 3 && v.MF == 32) return launch_wgrad_dma<32, 3, 9, 16>(a, nch, gy, st);
   if (KS == 3 && v.MF == 16) return launch_wgrad_dma<16, 3, 9, 16>(a, nch, gy, st);
+  if (KS == 5 && v.MF == 32 && v.TH == 4) return launch_wgrad_dma<32, 5, 5, 4>(a, nch, gy, st);
   if (KS == 5 && v.MF == 32) return launch_wgrad_dma<32, 5, 5, 8>(a, nch, gy, st);
   if (KS == 5 && v.MF == 16) return launch_wgrad_dma<16, 5, 25, 16>(a, nch, gy, st);
   if (KS == 1 && v.MF == 32) return launch_wgrad_dma<32, 1, 1, 16>(a, nch, gy, st);
